@@ -1,0 +1,264 @@
+/* vqwave.h -- C ABI of libvqwave.so: the MI355X (gfx950) hot path of VQ-VAE-WaveNet.
+ *
+ * The reference (StanislavParovoy/VQ-VAE-WaveNet) is pure Python on TensorFlow 1.x and
+ * has no FFI of its own; every entry point below replaces the TensorFlow-runtime work
+ * behind one reference call site, cited as `file:line` of /root/reference.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + explicit sizes + a hipStream_t passed as void*.
+ *   - every function returns 0 on success, non-zero on error (never throws, never
+ *     aborts); vqw_last_error() returns the message of the calling thread's last error.
+ *   - asynchronous on the given stream, no hidden synchronisation, no allocation;
+ *     the caller owns every buffer (except the opaque AR-decoder handle).
+ *   - activations are (batch, channel, time) fp32, time contiguous: x[b][c][t].
+ *     The reference's op surface is channels-last [B,T,C]; the Python mirror
+ *     transposes at that surface only.
+ *   - conv kernels keep the reference's variable layout kernel[k][Cin][Cout]
+ *     (wavenet_ops.py:66-69), row-major, i.e. one [Cin][Cout] matrix per tap.
+ */
+#ifndef VQWAVE_H
+#define VQWAVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vqw_stream_t; /* hipStream_t */
+
+#define VQW_ABI_VERSION 1
+#define VQW_MAX_TAPS 8
+
+const char* vqw_last_error(void);
+int vqw_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * mu-law companding -- reference mu_law_ops.py:5-31, wavenet_ops.py:9-14
+ * ---------------------------------------------------------------------------------- */
+/* y = sign(x) log1p(255|x|)/log1p(255), x clipped to [-1,1]   (mu_law_ops.py:6-8) */
+int vqw_mu_law_encode_f32(const float* x, float* y, size_t n, vqw_stream_t s);
+/* integer labels 0..255, bit-exact vs the fp32 formula via a threshold table
+ * (mu_law_ops.py:11) */
+int vqw_mu_law_encode_i32(const float* x, int32_t* y, size_t n, vqw_stream_t s);
+/* idx (float holding 0..256) -> sample in [-1,1]   (mu_law_ops.py:26-31) */
+int vqw_mu_law_decode_f32(const float* idx, float* x, size_t n, vqw_stream_t s);
+/* Fused decoder front end (wavenet.py:33-37): labels = encode_i32(x),
+ * inputs = encode_f32(shift_right(x)); x is [B][T]. Either output may be NULL. */
+int vqw_wavenet_inputs(const float* x, float* inputs, int32_t* labels, int B, int T,
+                       vqw_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution engine (fp32 MFMA) -- replaces tf.pad + tf.nn.conv2d + bias
+ * (wavenet_ops.py:81-89), add_condition (93-101), the gate (112-113), the 1x1 skip /
+ * residual convs + accumulation (132-136, wavenet.py:72-73), Keras Conv1D + BatchNorm
+ * (encoder.py:15-25) and their gradients (TF autodiff: Conv2DBackpropInput).
+ *
+ *   acc[b][m][t] = sum_{j<ntaps} sum_{c<C0+C1} w[j][c][m] * x[b][c][in_stride*t + tap_shift[j]]
+ *   (x = x0 for c < C0, x1 for c >= C0; reads outside [0,T_in) are zero)
+ * followed by one of the epilogues below.
+ * ---------------------------------------------------------------------------------- */
+enum {
+    VQW_EPI_STORE = 0,       /* v=acc+bias+cond; r=out_relu?max(v,0):v; save0=r;
+                                out=scale?scale*r+shift:r                                */
+    VQW_EPI_ACCUM_SPLIT = 1, /* v=acc+bias; rows<M0: out0+=v; rows>=M0: out1=aux1+v      */
+    VQW_EPI_GATE = 2,        /* M=2H rows (f,g pairs); out0=tanh(vf)*sigmoid(vg) [H rows];
+                                save0=tanh, save1=sigmoid                                */
+    VQW_EPI_GATE_BWD = 3,    /* M=H rows; v=acc (d gated); aux0=tanh, aux1=sigmoid;
+                                out0[row]=v*s*(1-t^2), out0[H+row]=v*t*s*(1-s)          */
+    VQW_EPI_MASK = 4         /* v=acc*(scale?scale[row]:1); out0 = aux0>0 ? v : 0        */
+};
+
+typedef struct vqw_conv_desc {
+    int32_t B, T_out, T_in;
+    int32_t M;        /* GEMM rows (output channels; 2H for GATE)                        */
+    int32_t C0, C1;   /* input channels taken from x0 / x1 (multiples of 16; C1 may be 0) */
+    int32_t ntaps, in_stride;
+    int32_t tap_shift[VQW_MAX_TAPS];
+    int32_t ldw;      /* row length of w (>= M, multiple of 4)                           */
+    int32_t in_relu;  /* relu applied to x while it is staged                            */
+    int32_t epilogue;
+    int32_t out_relu;
+    int32_t M0;       /* rows [0,M0) go to out0, [M0,M) to out1 (STORE / ACCUM_SPLIT)     */
+    int32_t out_tstride, out_toffset, T_store; /* store index = out_tstride*t+out_toffset,
+                                                  output rows have T_store elements      */
+    int32_t cond_T;   /* 0 = none; cond[b][row][t / (T_out/cond_T)] is added             */
+    int32_t tile;     /* 0 = auto; else 10*MT+NT (per-wave 32x32 tile counts)            */
+    int64_t cond_bstride; /* batch stride of cond in floats                              */
+    int64_t w_tap_stride; /* floats between consecutive taps of w; 0 = (C0+C1)*ldw       */
+    const float *x0, *x1, *w, *bias, *cond, *scale, *shift, *aux0, *aux1;
+    float *out0, *out1, *save0, *save1;
+} vqw_conv_desc;
+
+int vqw_conv_gemm(const vqw_conv_desc* d, vqw_stream_t s);
+
+/* Weight-gradient engine (TF autodiff: Conv2DBackpropFilter), split-K with fp32 atomics:
+ *   dw[j][c][o] += sum_{b,t<T_q} p[b][c][p_stride*t + tap_shift[j]] * q[b][o][t]
+ * (q = q0 for o < Q0, q1 above).  dw must be pre-zeroed / holds the running sum. */
+typedef struct vqw_wgrad_desc {
+    int32_t B, T_q, T_p;
+    int32_t Cp;       /* rows of dw (input channels)                                     */
+    int32_t Q0, Q1;   /* columns of dw taken from q0 / q1                                */
+    int32_t ntaps, p_stride;
+    int32_t tap_shift[VQW_MAX_TAPS];
+    int32_t p_relu;   /* relu applied to p while it is staged                            */
+    int32_t lddw;
+    int32_t splits;   /* 0 = auto: time chunks per batch element                         */
+    int64_t dw_tap_stride;
+    const float *p, *q0, *q1;
+    float* dw;
+} vqw_wgrad_desc;
+
+int vqw_wgrad_gemm(const vqw_wgrad_desc* d, vqw_stream_t s);
+
+/* Named wrappers with the reference's argument meaning --------------------------------
+ * conv1d_v2 (wavenet_ops.py:59-90): causal left pad d*(k-1), stride, dilation, +bias.
+ * x [B][Cin][T], w [k][Cin][Cout], y [B][Cout][ceil(T/stride)].                       */
+int vqw_causal_conv1d_fwd(const float* x, const float* w, const float* bias, float* y,
+                          int B, int Cin, int Cout, int T, int k, int dilation, int stride,
+                          vqw_stream_t s);
+/* dx[b][c][t] = sum_j sum_o wT[j][o][c] * dy[b][o][t + (k-1-j)*dilation]; wT = per-tap
+ * transposed kernel [k][Cout][Cin] (see vqw_transpose).  stride 1 only.               */
+int vqw_causal_conv1d_dgrad(const float* dy, const float* wT, float* dx, int B, int Cin,
+                            int Cout, int T, int k, int dilation, vqw_stream_t s);
+int vqw_causal_conv1d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin,
+                            int Cout, int T, int k, int dilation, vqw_stream_t s);
+/* Keras Conv1D (encoder.py:15-19, encoder_ops.py:46-70) with explicit TF-SAME pads:
+ * y[b][o][t] = bias[o] + sum_j sum_c w[j][c][o] x[b][c][stride*t + j - pad_left].     */
+int vqw_conv1d_same_fwd(const float* x, const float* w, const float* bias, float* y, int B,
+                        int Cin, int Cout, int T_in, int T_out, int k, int stride,
+                        int pad_left, int relu, vqw_stream_t s);
+int vqw_conv1d_same_dgrad(const float* dy, const float* wT, float* dx, int B, int Cin,
+                          int Cout, int T_in, int T_out, int k, int stride, int pad_left,
+                          vqw_stream_t s);
+int vqw_conv1d_same_wgrad(const float* x, const float* dy, float* dw, int B, int Cin,
+                          int Cout, int T_in, int T_out, int k, int stride, int pad_left,
+                          vqw_stream_t s);
+/* 1x1 conv == channel-mixing GEMM (wavenet_ops.py:132-136, `linear` 147-160).
+ * accumulate != 0: y += result.                                                        */
+int vqw_pointwise_gemm_fwd(const float* x, const float* w, const float* bias, float* y,
+                           int B, int Cin, int Cout, int T, int relu_in, int accumulate,
+                           vqw_stream_t s);
+int vqw_pointwise_gemm_dgrad(const float* dy, const float* wT, float* dx, int B, int Cin,
+                             int Cout, int T, vqw_stream_t s);
+int vqw_pointwise_gemm_wgrad(const float* x, const float* dy, float* dw, int B, int Cin,
+                             int Cout, int T, int relu_in, vqw_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * Small convs with Cin == 1 (decoder preprocess wavenet.py:42-44, encoder.py:15 layer 1):
+ *   v = bias[f] + sum_j w[j][f] * x[b][stride*t + j + offset];   r = relu ? max(v,0) : v
+ *   save_r (optional) = r;  out = scale ? scale[f]*r + shift[f] : r
+ * x [B][T_in], w [k][F], out [B][F][T_out].                                            */
+int vqw_conv_cin1_fwd(const float* x, const float* w, const float* bias, const float* scale,
+                      const float* shift, float* out, float* save_r, int B, int T_in,
+                      int T_out, int F, int k, int stride, int offset, int relu,
+                      vqw_stream_t s);
+/* dw[j][f] += sum_{b,t} x[b][stride*t+j+offset] * dout[b][f][t] */
+int vqw_conv_cin1_wgrad(const float* x, const float* dout, float* dw, int B, int T_in,
+                        int T_out, int F, int k, int stride, int offset, vqw_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * Row reductions over (b, t) of a [B][C][T] tensor (bias / BN gradients, and the
+ * transpose of add_condition's nearest-neighbour upsampling, wavenet_ops.py:98-100):
+ *   seg_out[b][c][t/seg] = sum over the segment of x*(y?y:1)   (optional, seg | T)
+ *   total[c]            += alpha * sum_{b,t} x*(y?y:1)         (optional)               */
+int vqw_rowsum(const float* x, const float* y, float* seg_out, float* total, float alpha,
+               int B, int C, int T, int seg, vqw_stream_t s);
+
+/* dst[b][c][r] = src[b][r][c]  (batched 2-D transpose; per-tap kernel transposes) */
+int vqw_transpose(const float* src, float* dst, int batch, int rows, int cols,
+                  vqw_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * VQ nearest codebook entry -- model.py:57-74.
+ * z_e [B][D][Tz]; emb [K][D].  dist = sum_{d=0..D-1} (z-e)^2 accumulated sequentially in
+ * fp32 with separately rounded multiply and add; idx = lowest index of the minimum.
+ * Outputs: idx int64 [B][Tz]; e_k [B][D][Tz]; z_q = z_e + (e_k - z_e) written to
+ * zq[b*zq_bstride + d*Tz + t] (so it can land inside the decoder condition tensor);
+ * mind [B][Tz] = winning distance.                                                     */
+int vqw_vq_nearest_fwd(const float* z_e, const float* emb, int64_t* idx, float* e_k,
+                       float* zq, int64_t zq_bstride, float* mind, int B, int D, int Tz,
+                       int K, vqw_stream_t s);
+/* Gradients of model.py:73,100,103 (Appendix A-5 of SURVEY.md):
+ *   dz_e = dzq + cscale*(z_e - e_k);   demb[idx] += escale*(e_k - z_e)                  */
+int vqw_vq_nearest_bwd(const float* z_e, const float* e_k, const int64_t* idx,
+                       const float* dzq, int64_t dzq_bstride, float* dz_e, float* demb,
+                       float cscale, float escale, int B, int D, int Tz, int K,
+                       vqw_stream_t s);
+/* Speaker path, model.py:22-27 + decoder_ops.py:39-43:
+ * cond[b*cond_bstride + (row0+j)*Tz + t] = table[spk[b]][j] for all t.                  */
+int vqw_speaker_tile_fwd(const float* table, const int64_t* spk, float* cond,
+                         int64_t cond_bstride, int row0, int B, int Cs, int Tz,
+                         vqw_stream_t s);
+/* dtable[spk[b]][j] += sum_t dcond[b][row0+j][t] */
+int vqw_speaker_tile_bwd(const float* dcond, int64_t dcond_bstride, int row0,
+                         const int64_t* spk, float* dtable, int B, int Cs, int Tz,
+                         vqw_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * Softmax cross-entropy over the channel axis -- model.py:91-94.
+ * logits [B][Q][T], labels int32 [B][T].  loss_sum[0] += sum_{b,t} CE;
+ * dlogits (optional, may alias logits) = (softmax - onehot) * grad_scale;
+ * probs (optional) = softmax.                                                          */
+int vqw_softmax_xent(const float* logits, const int32_t* labels, float* dlogits,
+                     float* probs, float* loss_sum, float grad_scale, int B, int Q, int T,
+                     vqw_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * Fused TF-1.x Adam + ExponentialMovingAverage step over a flat buffer --
+ * model.py:116-128:
+ *   g = grad*grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   p -= lr_t * m / (sqrt(v) + eps);  ema -= (1-decay) * (ema - p)
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.                           */
+int vqw_adam_ema_step(float* param, const float* grad, float* m, float* v, float* ema,
+                      size_t n, float lr_t, float beta1, float beta2, float eps,
+                      float decay, float grad_scale, vqw_stream_t s);
+
+/* ------------------------------------------------------------------------------------
+ * Fast autoregressive generation -- wavenet.py:103-172, wavenet_ops.py:147-267,
+ * generate.py:103-113, utils.py:13-46.  The FIFO queues become device ring buffers.
+ * Weight layout: see vqw_ar_weights; all pointers are device pointers that must stay
+ * valid for the lifetime of the handle.
+ * ---------------------------------------------------------------------------------- */
+typedef struct vqw_ar_weights {
+    int32_t n_layers, kernel_size, R, S, Q, Cc, pre_k; /* residual(=dilation) filters R,
+                                                          skip S, quantisation Q         */
+    const int32_t* dilations;   /* HOST pointer, n_layers entries                        */
+    const float* pre_w;         /* [pre_k][R]           decoder/preprocess/kernel        */
+    const float* pre_b;         /* [R]                                                   */
+    const float* skip0_w;       /* [R][S]               decoder/skip/kernel              */
+    const float* skip0_b;       /* [S]                                                   */
+    const float* const* gated_w;   /* HOST array of n_layers device ptrs [k][R][2R]      */
+    const float* const* gated_b;   /* [2R]                                               */
+    const float* const* cond_w;    /* [Cc][2R]  row stride cond_ld                       */
+    const float* const* out_w;     /* [R][S+R]  skip|residual, row stride out_ld         */
+    const float* const* out_b;     /* [S+R]                                              */
+    int32_t cond_ld, out_ld;
+    const float* post1_w;       /* [S][S]                                                */
+    const float* post1_b;       /* [S]                                                   */
+    const float* post1_cond_w;  /* [Cc][S] row stride post1_cond_ld                      */
+    int32_t post1_cond_ld;
+    const float* post2_w;       /* [S][Q]                                                */
+    const float* post2_b;       /* [Q]                                                   */
+} vqw_ar_weights;
+
+typedef struct vqw_ar_decoder vqw_ar_decoder;
+
+int vqw_ar_decode_create(vqw_ar_decoder** out, const vqw_ar_weights* w, int batch);
+/* zero the queues (generate.py:105 sess.run(init_ops)) and restart at sample 0 */
+int vqw_ar_decode_reset(vqw_ar_decoder* h, vqw_stream_t s);
+/* Generate `n_steps` samples.  encoding [B][Cc][Tz] (model.encoding, channel-major);
+ * sample i uses encoding[:, :, (start+i)/ratio].  mode 0 = greedy (argmax), 1 = sample
+ * with caller-supplied uniforms u[B][n_steps] (searchsorted(cumsum(p), u), utils.py:20-25).
+ * Outputs: audio [B][n_steps] (mu-law decoded floats), indices int32 [B][n_steps]
+ * (optional), probs_last [B][Q] (optional: probabilities of the final step).           */
+int vqw_ar_decode_run(vqw_ar_decoder* h, const float* encoding, int Tz, int ratio,
+                      int n_steps, int mode, const float* uniforms, float* audio,
+                      int32_t* indices, float* probs_last, vqw_stream_t s);
+int vqw_ar_decode_destroy(vqw_ar_decoder* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQWAVE_H */

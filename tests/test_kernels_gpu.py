@@ -1,0 +1,363 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle.
+
+Tolerances: integer / index outputs are compared bit-exactly; fp32 MFMA results against the
+torch-CPU fp32 oracle within rtol 2e-4 / atol 2e-4 scaled by the operand magnitude (both sides
+accumulate K<=2304 fp32 products in different orders).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+from oracle import ref_model as M
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def g(t):
+    return t.contiguous().to(DEV)
+
+
+def bct(x_btc):
+    """[B,T,C] -> contiguous (B,C,T) on the GPU."""
+    return x_btc.transpose(1, 2).contiguous().to(DEV)
+
+
+def btc(x_bct):
+    return x_bct.detach().cpu().transpose(1, 2).contiguous()
+
+
+def close(a, b, rtol=2e-4, atol=2e-4, what=''):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= atol * scale + rtol * scale, '%s max abs err %.3e (scale %.3e)' % (what, err, scale)
+
+
+# ----------------------------------------------------------------------------- mu-law
+def test_mu_law_int_all_pcm_codes_bit_exact(K):
+    pcm = np.arange(-32768, 32768, dtype=np.int64)
+    xs = ((pcm.astype(np.float32) + np.float32(0.5)) / np.float32(32767.5)).astype(np.float32)
+    want = R.mu_law_encode_np(xs, to_int=True)
+    got = K.mu_law_encode_i32(g(torch.from_numpy(xs))).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_mu_law_int_random_and_edges_bit_exact(K):
+    rng = np.random.RandomState(0)
+    xs = np.concatenate([rng.uniform(-1.2, 1.2, 1 << 20).astype(np.float32),
+                         np.array([-2, -1, -0.0, 0.0, 1, 2, 1e-30, -1e-30, 0.999999, -0.999999], np.float32),
+                         np.nextafter(np.float32(1), np.float32(0), dtype=np.float32).reshape(1)])
+    want = R.mu_law_encode_np(xs, to_int=True)
+    got = K.mu_law_encode_i32(g(torch.from_numpy(xs))).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_mu_law_float_and_decode(K):
+    rng = np.random.RandomState(1)
+    xs = rng.uniform(-1.1, 1.1, 100000).astype(np.float32)
+    got = K.mu_law_encode_f32(g(torch.from_numpy(xs))).cpu().numpy()
+    np.testing.assert_allclose(got, R.mu_law_encode_np(xs), rtol=0, atol=3e-7)
+    idx = np.arange(0, 257, dtype=np.float32)
+    dec = K.mu_law_decode_f32(g(torch.from_numpy(idx))).cpu().numpy()
+    np.testing.assert_allclose(dec, R.mu_law_decode_np(idx), rtol=2e-6, atol=1e-7)
+
+
+def test_wavenet_inputs(K):
+    x, _, _ = M.synthetic_batch(3, 512, 10, 7)
+    xb = g(x[:, :, 0])
+    inputs = torch.empty_like(xb)
+    labels = torch.empty(xb.shape, dtype=torch.int32, device=DEV)
+    K.wavenet_inputs(xb, inputs, labels)
+    want_l = R.mu_law_encode_np(x[:, :, 0].numpy(), to_int=True)
+    assert np.array_equal(labels.cpu().numpy(), want_l)
+    want_i = R.mu_law_encode_np(R.shift_right(x)[:, :, 0].numpy())
+    np.testing.assert_allclose(inputs.cpu().numpy(), want_i, atol=3e-7)
+
+
+def test_empty_inputs_are_ok(K):
+    e = torch.empty(0, device=DEV)
+    assert K.mu_law_encode_f32(e).numel() == 0
+    assert K.mu_law_encode_i32(e).numel() == 0
+
+
+# ----------------------------------------------------------------------------- VQ
+@pytest.mark.parametrize('B,Tz,D,Kc', [(2, 8, 16, 32), (8, 104, 64, 512), (3, 5, 64, 100)])
+def test_vq_nearest_bit_exact(K, B, Tz, D, Kc):
+    rng = np.random.RandomState(3)
+    z = torch.from_numpy(rng.standard_normal((B, Tz, D)).astype(np.float32) * 0.2)
+    emb = torch.from_numpy(rng.uniform(-0.13, 0.13, (Kc, D)).astype(np.float32))
+    emb[7] = emb[3]                       # exact tie between two codes: lowest index must win
+    z[0, 0] = emb[7]
+    q, e_k, z_q = M.discretise(z, emb)
+    zb = bct(z)
+    idx = torch.empty(B, Tz, dtype=torch.int64, device=DEV)
+    ek = torch.empty(B, D, Tz, device=DEV)
+    zq = torch.empty(B, D, Tz, device=DEV)
+    mind = torch.empty(B, Tz, device=DEV)
+    K.vq_nearest_fwd(zb, g(emb), idx=idx, e_k=ek, zq=zq, mind=mind)
+    assert torch.equal(idx.cpu(), q)
+    assert int(idx[0, 0]) == 3
+    assert torch.equal(btc(ek), e_k)
+    assert torch.equal(btc(zq), z_q)      # z_e + (e_k - z_e), same rounding
+    d = M.vq_distances_np(z.reshape(-1, D).numpy(), emb.numpy()).min(-1)
+    assert np.array_equal(mind.cpu().numpy().reshape(-1), d)
+
+
+def test_vq_bwd_and_speaker(K):
+    rng = np.random.RandomState(4)
+    B, Tz, D, Kc, Cs, S = 2, 8, 16, 32, 16, 5
+    z = torch.from_numpy(rng.standard_normal((B, D, Tz)).astype(np.float32)).to(DEV)
+    emb = torch.from_numpy(rng.standard_normal((Kc, D)).astype(np.float32)).to(DEV)
+    idx = torch.empty(B, Tz, dtype=torch.int64, device=DEV)
+    ek = torch.empty(B, D, Tz, device=DEV)
+    K.vq_nearest_fwd(z, emb, idx=idx, e_k=ek)
+    Cc = D + Cs
+    dcond = torch.from_numpy(rng.standard_normal((B, Cc, Tz)).astype(np.float32)).to(DEV)
+    dz = torch.empty_like(z)
+    demb = torch.zeros(Kc, D, device=DEV)
+    K.vq_nearest_bwd(z, ek, idx, dzq=dcond, dzq_bstride=Cc * Tz, dz_e=dz, demb=demb, cscale=0.3, escale=0.7, K=Kc)
+    want_dz = dcond[:, :D] + 0.3 * (z - ek)
+    close(dz, want_dz, what='dz_e')
+    want_demb = torch.zeros(Kc, D, device=DEV)
+    want_demb.index_add_(0, idx.reshape(-1), (0.7 * (ek - z)).permute(0, 2, 1).reshape(-1, D))
+    close(demb, want_demb, what='demb')
+    table = torch.from_numpy(rng.standard_normal((S, Cs)).astype(np.float32)).to(DEV)
+    spk = torch.tensor([4, 1], dtype=torch.int64, device=DEV)
+    cond = torch.zeros(B, Cc, Tz, device=DEV)
+    K.speaker_tile_fwd(table, spk, cond, cond_bstride=Cc * Tz, row0=D, Cs=Cs, Tz=Tz)
+    assert torch.equal(cond[:, D:], table[spk][:, :, None].expand(-1, -1, Tz))
+    assert float(cond[:, :D].abs().max()) == 0.0
+    dt = torch.zeros(S, Cs, device=DEV)
+    K.speaker_tile_bwd(dcond, spk, dt, dcond_bstride=Cc * Tz, row0=D, Cs=Cs, Tz=Tz)
+    want = torch.zeros(S, Cs, device=DEV)
+    want.index_add_(0, spk, dcond[:, D:].sum(-1))
+    close(dt, want, what='dspeaker')
+
+
+# ----------------------------------------------------------------------------- conv engine
+def rnd(*shape, seed=0, s=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * s)
+
+
+CONV_CASES = [
+    # B, T, Cin, Cout, k, dilation, tile
+    (2, 512, 32, 64, 3, 1, 0),
+    (2, 512, 32, 64, 3, 4, 24),
+    (1, 1024, 64, 128, 3, 512, 24),     # dilation larger than the tile: whole taps skipped
+    (2, 260, 48, 68, 2, 3, 22),         # ragged T and channel counts
+    (2, 512, 32, 64, 1, 1, 12),
+    (1, 6656, 256, 512, 3, 64, 0),      # full-size decoder layer (B=1)
+]
+
+
+@pytest.mark.parametrize('B,T,Cin,Cout,k,dil,tile', CONV_CASES)
+def test_causal_conv_fwd_matches_oracle(K, B, T, Cin, Cout, k, dil, tile):
+    x, w, b = rnd(B, T, Cin, seed=1), rnd(k, Cin, Cout, seed=2, s=(k * Cin) ** -0.5), rnd(Cout, seed=3)
+    want = R.conv1d_v2(x, w, b, dilations=dil)
+    out = torch.full((B, Cout, T), float('nan'), device=DEV)
+    K.conv_gemm(x0=bct(x), w=g(w), bias=g(b), out0=out, B=B, T_in=T, T_out=T, M=Cout, C0=Cin,
+                taps=[-(k - 1 - j) * dil for j in range(k)], tile=tile)
+    close(btc(out), want, what='conv fwd')
+
+
+def test_named_wrappers_causal(K, pkg):
+    L = pkg._lib
+    B, T, Cin, Cout, k, dil = 2, 384, 32, 64, 3, 2
+    x, w, b = rnd(B, T, Cin, seed=1), rnd(k, Cin, Cout, seed=2, s=0.1), rnd(Cout, seed=3)
+    xb, wb, bb = bct(x), g(w), g(b)
+    y = torch.empty(B, Cout, T, device=DEV)
+    L.check(L.lib().vqw_causal_conv1d_fwd(L.ptr(xb), L.ptr(wb), L.ptr(bb), L.ptr(y), B, Cin, Cout, T, k, dil, 1, L.stream()))
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    yo = R.conv1d_v2(xr, wr, b, dilations=dil)
+    close(btc(y), yo, what='wrapper fwd')
+    dy = rnd(B, T, Cout, seed=9)
+    yo.backward(dy)
+    wT = torch.empty(k, Cout, Cin, device=DEV)
+    K.transpose(wb, wT, k, Cin, Cout)
+    assert torch.equal(wT.cpu(), w.transpose(1, 2))
+    dx = torch.empty(B, Cin, T, device=DEV)
+    dyb = bct(dy)
+    L.check(L.lib().vqw_causal_conv1d_dgrad(L.ptr(dyb), L.ptr(wT), L.ptr(dx), B, Cin, Cout, T, k, dil, L.stream()))
+    close(btc(dx), xr.grad, what='wrapper dgrad')
+    dw = torch.zeros(k, Cin, Cout, device=DEV)
+    L.check(L.lib().vqw_causal_conv1d_wgrad(L.ptr(xb), L.ptr(dyb), L.ptr(dw), B, Cin, Cout, T, k, dil, L.stream()))
+    close(dw, wr.grad, rtol=5e-4, atol=5e-4, what='wrapper wgrad')
+    # stride 2 (conv1d_v2 with stride, Encoder_Magenta use)
+    y2 = torch.empty(B, Cout, T // 2, device=DEV)
+    L.check(L.lib().vqw_causal_conv1d_fwd(L.ptr(xb), L.ptr(wb), L.ptr(bb), L.ptr(y2), B, Cin, Cout, T, k, dil, 2, L.stream()))
+    close(btc(y2), R.conv1d_v2(x, w, b, dilations=dil, stride=2), what='wrapper fwd stride 2')
+
+
+def test_bad_arguments_return_errors_not_faults(K, pkg):
+    L = pkg._lib
+    x = torch.zeros(1, 24, 64, device=DEV)
+    with pytest.raises(RuntimeError, match='multiples of 16'):
+        K.conv_gemm(x0=x, w=torch.zeros(24, 16, device=DEV), out0=torch.zeros(1, 16, 64, device=DEV),
+                    B=1, T_in=64, T_out=64, M=16, C0=24, taps=[0])
+    with pytest.raises(ValueError, match='elements'):
+        K.conv_gemm(x0=x, w=torch.zeros(4, device=DEV), out0=torch.zeros(1, 16, 64, device=DEV),
+                    B=1, T_in=64, T_out=64, M=16, C0=16, taps=[0])
+    assert L.lib().vqw_conv_gemm(None, None) != 0
+
+
+@pytest.mark.parametrize('T,tile', [(512, 24), (384, 22)])
+def test_gate_epilogue_with_condition(K, T, tile):
+    B, Cin, H, Cc, ratio = 2, 32, 32, 16, 64
+    Tz = T // ratio
+    x, w, b = rnd(B, T, Cin, seed=1), rnd(3, Cin, 2 * H, seed=2, s=0.1), rnd(2 * H, seed=3, s=0.3)
+    cond, wc = rnd(B, Tz, Cc, seed=4), rnd(1, Cc, 2 * H, seed=5, s=0.2)
+    p = {'gated/kernel': w, 'gated/bias': b, 'gated/local_condition/kernel': wc}
+    want = R.gated_cnn(x, p, H, 2, cond)
+    enc = R.conv1d_v2(cond, wc)                                  # [B,Tz,2H]
+    out = torch.empty(B, H, T, device=DEV); th = torch.empty_like(out); sg = torch.empty_like(out)
+    K.conv_gemm(x0=bct(x), w=g(w), bias=g(b), out0=out, save0=th, save1=sg, B=B, T_in=T, T_out=T, M=2 * H,
+                C0=Cin, taps=[-4, -2, 0], epilogue=K.EPI_GATE, cond=bct(enc), cond_T=Tz, tile=tile)
+    close(btc(out), want, atol=2e-5, rtol=2e-5, what='gated')
+    close(th * sg, out, atol=1e-6, rtol=0, what='saved tanh*sigmoid')
+
+
+def test_accum_split_and_two_sources(K):
+    B, T, Cg, S, Rr = 2, 512, 32, 64, 32
+    gated, w, b = rnd(B, T, Cg, seed=1), rnd(Cg, S + Rr, seed=2, s=0.2), rnd(S + Rr, seed=3)
+    skip0, net0 = rnd(B, T, S, seed=4), rnd(B, T, Rr, seed=5)
+    want = gated @ w + b
+    skip = bct(skip0); net_in = bct(net0); net_out = torch.empty_like(net_in)
+    K.conv_gemm(x0=bct(gated), w=g(w), bias=g(b), out0=skip, out1=net_out, aux1=net_in, B=B, T_in=T, T_out=T,
+                M=S + Rr, M0=S, C0=Cg, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
+    close(btc(skip), skip0 + want[..., :S], what='skip +=')
+    close(btc(net_out), net0 + want[..., S:], what='net = net + res')
+    # dgated = [dskip; dnet] x Wcat^T with the two sources concatenated along K, gate backward epilogue
+    dskip, dnet = rnd(B, T, S, seed=6), rnd(B, T, Rr, seed=7)
+    th, sg = torch.tanh(rnd(B, T, Cg, seed=8)), torch.sigmoid(rnd(B, T, Cg, seed=9))
+    dg = torch.cat([dskip, dnet], -1) @ w.t()
+    want_pre = torch.cat([dg * sg * (1 - th * th), dg * th * sg * (1 - sg)], -1)
+    wT = g(w.t().contiguous())
+    dpre = torch.empty(B, 2 * Cg, T, device=DEV)
+    K.conv_gemm(x0=bct(dskip), x1=bct(dnet), w=wT, out0=dpre, aux0=bct(th), aux1=bct(sg), B=B, T_in=T, T_out=T,
+                M=Cg, C0=S, C1=Rr, taps=[0], epilogue=K.EPI_GATE_BWD)
+    close(btc(dpre), want_pre, what='gate backward')
+
+
+def test_mask_relu_in_and_bn_epilogues(K):
+    B, T, Cin, Cout = 2, 256, 32, 64
+    x, w, b = rnd(B, T, Cin, seed=1), rnd(1, Cin, Cout, seed=2, s=0.2), rnd(Cout, seed=3)
+    sc, sh = rnd(Cout, seed=4), rnd(Cout, seed=5)
+    out = torch.empty(B, Cout, T, device=DEV); r = torch.empty_like(out)
+    K.conv_gemm(x0=bct(x), w=g(w), bias=g(b), scale=g(sc), shift=g(sh), out0=out, save0=r, B=B, T_in=T, T_out=T,
+                M=Cout, C0=Cin, taps=[0], in_relu=True, out_relu=True)
+    rr = torch.relu(torch.relu(x) @ w[0] + b)
+    close(btc(r), rr, what='relu out')
+    close(btc(out), rr * sc + sh, what='bn affine')
+    aux = rnd(B, T, Cout, seed=6)
+    K.conv_gemm(x0=bct(x), w=g(w), scale=g(sc), out0=out, aux0=bct(aux), B=B, T_in=T, T_out=T, M=Cout, C0=Cin,
+                taps=[0], epilogue=K.EPI_MASK)
+    close(btc(out), (x @ w[0]) * sc * (aux > 0), what='mask')
+
+
+@pytest.mark.parametrize('T_in,k,stride', [(512, 5, 2), (208, 5, 2), (256, 4, 2), (250, 5, 2), (256, 3, 1)])
+def test_keras_same_conv_fwd_dgrad_wgrad(K, pkg, T_in, k, stride):
+    L = pkg._lib
+    B, Cin, Cout = 2, 32, 48
+    pl, pr = R.same_pads(T_in, k, stride)
+    T_out = -(-T_in // stride)
+    x, w, b = rnd(B, T_in, Cin, seed=1), rnd(k, Cin, Cout, seed=2, s=0.1), rnd(Cout, seed=3)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    yo = R.keras_conv1d(xr, wr, b, stride=stride, padding='same', relu=False)
+    xb, wb, bb = bct(x), g(w), g(b)
+    y = torch.empty(B, Cout, T_out, device=DEV)
+    L.check(L.lib().vqw_conv1d_same_fwd(L.ptr(xb), L.ptr(wb), L.ptr(bb), L.ptr(y), B, Cin, Cout, T_in, T_out, k,
+                                        stride, pl, 0, L.stream()))
+    close(btc(y), yo, what='same fwd')
+    dy = rnd(B, T_out, Cout, seed=7)
+    yo.backward(dy)
+    wT = torch.empty(k, Cout, Cin, device=DEV)
+    K.transpose(wb, wT, k, Cin, Cout)
+    dx = torch.full((B, Cin, T_in), float('nan'), device=DEV)
+    dyb = bct(dy)
+    L.check(L.lib().vqw_conv1d_same_dgrad(L.ptr(dyb), L.ptr(wT), L.ptr(dx), B, Cin, Cout, T_in, T_out, k, stride,
+                                          pl, L.stream()))
+    close(btc(dx), xr.grad, what='same dgrad')
+    dw = torch.zeros(k, Cin, Cout, device=DEV)
+    L.check(L.lib().vqw_conv1d_same_wgrad(L.ptr(xb), L.ptr(dyb), L.ptr(dw), B, Cin, Cout, T_in, T_out, k, stride,
+                                          pl, L.stream()))
+    close(dw, wr.grad, rtol=5e-4, atol=5e-4, what='same wgrad')
+
+
+def test_wgrad_two_sources_relu_and_full_size(K):
+    B, T, Cp, Q0, Q1 = 2, 512, 32, 64, 32
+    p, q0, q1 = rnd(B, T, Cp, seed=1), rnd(B, T, Q0, seed=2), rnd(B, T, Q1, seed=3)
+    want = torch.einsum('btc,bto->co', torch.relu(p), torch.cat([q0, q1], -1))
+    dw = torch.zeros(Cp, Q0 + Q1, device=DEV)
+    K.wgrad_gemm(p=bct(p), q0=bct(q0), q1=bct(q1), dw=dw, B=B, T_q=T, T_p=T, Cp=Cp, Q0=Q0, Q1=Q1, taps=[0], p_relu=True)
+    close(dw, want, rtol=5e-4, atol=5e-4, what='wgrad 2 sources')
+    # full-size decoder layer slice: B=1, T=6656, 256 -> 512, k=3, dilation 512
+    T, d = 6656, 512
+    x, dy = rnd(1, T, 256, seed=4), rnd(1, T, 512, seed=5)
+    xr = x.clone(); wz = torch.zeros(3, 256, 512, requires_grad=True)
+    R.conv1d_v2(xr, wz, None, dilations=d).backward(dy)
+    dw = torch.zeros(3, 256, 512, device=DEV)
+    K.wgrad_gemm(p=bct(x), q0=bct(dy), dw=dw, B=1, T_q=T, T_p=T, Cp=256, Q0=512, taps=[-2 * d, -d, 0])
+    close(dw, wz.grad, rtol=1e-3, atol=1e-3, what='wgrad full size')
+
+
+# ----------------------------------------------------------------------------- small kernels
+def test_conv_cin1_fwd_and_wgrad(K):
+    B, T, F, k = 2, 520, 32, 32
+    x, w, b = rnd(B, T, 1, seed=1), rnd(k, 1, F, seed=2, s=0.2), rnd(F, seed=3)
+    wr = w.clone().requires_grad_(True)
+    yo = R.conv1d_v2(x, wr, b)
+    out = torch.empty(B, F, T, device=DEV)
+    xb = g(x[:, :, 0])
+    K.conv_cin1_fwd(xb, g(w.reshape(k, F)), g(b), out, k=k, stride=1, offset=-(k - 1))
+    close(btc(out), yo, what='preprocess fwd')
+    dy = rnd(B, T, F, seed=4)
+    yo.backward(dy)
+    dw = torch.zeros(k, F, device=DEV)
+    K.conv_cin1_wgrad(xb, bct(dy), dw, k=k, stride=1, offset=-(k - 1))
+    close(dw, wr.grad.reshape(k, F), rtol=5e-4, atol=5e-4, what='preprocess wgrad')
+    # encoder layer 1: k=5, stride 2, SAME (pads 1,2), relu + BN affine
+    k, Fo = 5, 48
+    w1, b1, sc, sh = rnd(k, 1, Fo, seed=5, s=0.3), rnd(Fo, seed=6, s=0.1), rnd(Fo, seed=7), rnd(Fo, seed=8)
+    w1r = w1.clone().requires_grad_(True)
+    r = R.keras_conv1d(x, w1r, b1, stride=2, padding='same', relu=True)
+    out = torch.empty(B, Fo, T // 2, device=DEV); sr = torch.empty_like(out)
+    K.conv_cin1_fwd(xb, g(w1.reshape(k, Fo)), g(b1), out, k=k, stride=2, offset=-1, relu=True, scale=g(sc), shift=g(sh), save_r=sr)
+    close(btc(sr), r, what='enc1 relu')
+    close(btc(out), r * sc + sh, what='enc1 bn')
+
+
+def test_rowsum_transpose_softmax_adam(K):
+    B, Cc, T = 3, 20, 448
+    x, y = rnd(B, Cc, T, seed=1), rnd(B, Cc, T, seed=2)
+    seg = torch.empty(B, Cc, T // 64, device=DEV); tot = torch.ones(Cc, device=DEV)
+    K.rowsum(g(x), y=g(y), seg_out=seg, total=tot, alpha=0.5, seg=64)
+    close(seg, (x * y).reshape(B, Cc, T // 64, 64).sum(-1), what='segsum')
+    close(tot, 1 + 0.5 * (x * y).sum((0, 2)), rtol=1e-4, atol=1e-4, what='rowsum total')
+    tot2 = torch.zeros(Cc, device=DEV)
+    K.rowsum(g(x[:, :, :104].contiguous()), total=tot2)
+    close(tot2, x[:, :, :104].sum((0, 2)), what='rowsum T=104')
+    # softmax cross-entropy
+    B, Q, T = 2, 256, 200
+    lg = rnd(B, Q, T, seed=3, s=3.0); lab = torch.from_numpy(np.random.RandomState(4).randint(0, Q, (B, T)).astype(np.int32))
+    lr = lg.clone().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(lr.permute(0, 2, 1).reshape(-1, Q), lab.reshape(-1).long(), reduction='sum')
+    loss.backward()
+    ls = torch.zeros(1, device=DEV); dl = torch.empty(B, Q, T, device=DEV); pr = torch.empty_like(dl)
+    K.softmax_xent(g(lg), g(lab), loss_sum=ls, dlogits=dl, probs=pr, grad_scale=0.25)
+    close(ls, loss.detach().reshape(1), rtol=1e-5, atol=1e-5, what='CE loss')
+    close(dl, 0.25 * lr.grad, atol=1e-6, rtol=1e-5, what='dlogits')
+    close(pr, torch.softmax(lg, 1), atol=1e-6, rtol=1e-5, what='probs')
+    # Adam + EMA, two steps, n not a multiple of 4
+    n = 1003
+    p0, gr = rnd(n, seed=5), rnd(n, seed=6)
+    P = {'w': p0.clone()}; st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
+    pd, md, vd = g(p0.clone()), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ed = pd.clone()
+    for t in (1, 2):
+        M.adam_ema_step(P, {'w': gr * t}, st, 1e-3)
+        lr_t = 1e-3 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+        K.adam_ema_step(pd, g(gr * t), md, vd, ed, lr_t=lr_t)
+    close(pd, P['w'], atol=1e-6, rtol=1e-6, what='adam param')
+    close(ed, st['ema']['w'], atol=1e-6, rtol=1e-6, what='ema')

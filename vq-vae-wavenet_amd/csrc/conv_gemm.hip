@@ -1,0 +1,506 @@
+// Implicit-GEMM convolution engine for gfx950 (MI355X), true-fp32 MFMA.
+//
+// Replaces the TensorFlow runtime work behind the reference's conv call sites:
+// wavenet_ops.py:81-89 (tf.pad + tf.nn.conv2d + bias), 93-101 (add_condition),
+// 112-113 (gate), 132-136 + wavenet.py:72-73 (1x1 skip/residual + accumulation),
+// encoder.py:15-25 (Conv1D + relu + BatchNorm) and their input gradients.
+//
+// GEMM view (per batch element):  D[m][t] = sum_k Wt[m][k] * X[k][t],  k = (tap, channel)
+//   MFMA A operand = weights  (rows m = output channels), staged in LDS as As[k][m]
+//   MFMA B operand = activations (cols t = time),          staged in LDS as Bs[k][t]
+// Both LDS images are k-major with the MFMA row/col index contiguous, which is exactly the
+// global layout of kernel[k][Cin][Cout] and of (batch, channel, time) activations: global
+// reads are full-line coalesced and the dilation of a tap is only a shifted start address
+// of the staged window ("LDS-staged dilation windows").
+//
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31].  A wave
+// owns MT x NT tiles of 32x32; tile e of the M direction holds rows m = MT*r + e and tile f
+// of the N direction holds columns t = NT*c + f, so one ds_read_b64/b128 per lane fetches
+// the operands of all MT (NT) tiles and every accumulator row stores NT contiguous floats.
+#include "vqw_common.h"
+
+namespace {
+
+constexpr int BK = 16;  // channels per K-step
+
+struct ConvArgs {
+    vqw_conv_desc d;
+    int n_mt, n_nt, nwg;
+    int H;       // GATE / GATE_BWD: half width
+    int ratio;   // cond: T_out / cond_T
+    int vec_ok;  // output rows allow aligned vector stores
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+
+// 4 activations x[stride*t + ...] for 4 consecutive output times, zero outside [0,T_in).
+__device__ __forceinline__ f32x4 load_x4(const float* __restrict__ row, int ti, int T_in,
+                                         int stride, int relu) {
+    f32x4 v;
+    if (stride == 1) {
+        if (ti >= 0 && ti + 3 < T_in) {
+            const F4U u = *reinterpret_cast<const F4U*>(row + ti);
+            v = {u.x, u.y, u.z, u.w};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tt = ti + e;
+                v[e] = (tt >= 0 && tt < T_in) ? row[tt] : 0.0f;
+            }
+        }
+    } else {
+        if (ti >= 0 && ti + 7 < T_in) {
+            const F4U u0 = *reinterpret_cast<const F4U*>(row + ti);
+            const F4U u1 = *reinterpret_cast<const F4U*>(row + ti + 4);
+            v = {u0.x, u0.z, u1.x, u1.z};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tt = ti + stride * e;
+                v[e] = (tt >= 0 && tt < T_in) ? row[tt] : 0.0f;
+            }
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    return v;
+}
+
+template <int NT>
+__device__ __forceinline__ void store_row(float* __restrict__ rowp, int tb, int T_out,
+                                          int tstride, int toff, int vec_ok,
+                                          const float (&v)[NT]) {
+    if (vec_ok && tb + NT <= T_out) {
+        if constexpr (NT == 4) {
+            *reinterpret_cast<f32x4*>(rowp + tb) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            *reinterpret_cast<f32x2*>(rowp + tb) = f32x2{v[0], v[1]};
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < NT; ++f)
+            if (tb + f < T_out) rowp[tstride * (tb + f) + toff] = v[f];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_row(const float* __restrict__ rowp, int tb, int T_out,
+                                         int tstride, int toff, int vec_ok, float (&v)[NT]) {
+    if (vec_ok && tb + NT <= T_out) {
+        if constexpr (NT == 4) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(rowp + tb);
+            v[0] = u[0]; v[1] = u[1]; v[2] = u[2]; v[3] = u[3];
+        } else {
+            const f32x2 u = *reinterpret_cast<const f32x2*>(rowp + tb);
+            v[0] = u[0]; v[1] = u[1];
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < NT; ++f)
+            v[f] = (tb + f < T_out) ? rowp[tstride * (tb + f) + toff] : 0.0f;
+    }
+}
+
+template <int MT, int NT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int BM = 64 * MT, BN = 64 * NT;
+    constexpr int A_F4 = (BK * BM / 4) / 256;  // float4 per thread, weight tile
+    constexpr int B_F4 = (BK * BN / 4) / 256;  // float4 per thread, activation tile
+    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small");
+    static_assert(EPI != VQW_EPI_GATE || MT == 2, "gate epilogue pairs two M tiles");
+    constexpr bool GATE = (EPI == VQW_EPI_GATE);
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    float* const As = smem;
+    float* const Bs = smem + 2 * BK * BM;
+
+    const vqw_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // block -> (m tile, n tile, batch); m fastest so co-scheduled blocks share the
+    // activation panel in one XCD's L2.
+    int L = vqw_xcd_remap(blockIdx.x, a.nwg);
+    const int mt = L % a.n_mt;
+    L /= a.n_mt;
+    const int nt = L % a.n_nt;
+    const int b = L / a.n_nt;
+    const int t0 = nt * BN;
+    const int o0 = GATE ? mt * (BM / 2) : mt * BM;  // first output row / gated channel
+    const int Ctot = d.C0 + d.C1;
+    const int kchunks = Ctot / BK;
+
+    // taps whose staged window lies entirely outside [0,T_in) contribute nothing: skip them
+    unsigned act = 0;
+    int nact = 0;
+    {
+        const int tl = min(t0 + BN, d.T_out) - 1;
+        for (int j = 0; j < d.ntaps; ++j) {
+            const int lo = d.in_stride * t0 + d.tap_shift[j];
+            const int hi = d.in_stride * tl + d.tap_shift[j];
+            if (hi >= 0 && lo < d.T_in) { act |= 1u << j; ++nact; }
+        }
+    }
+    const int nsteps = nact * kchunks;
+
+    f32x4 ra[A_F4], rb[B_F4];
+
+    auto next_tap = [&](int j) {
+        ++j;
+        while (j < d.ntaps && !((act >> j) & 1u)) ++j;
+        return j;
+    };
+
+    auto load_tiles = [&](int tap, int kc) {
+        // ---- weights
+        if constexpr (GATE) {
+            const int kk = tid / (BM / 8), u2 = tid % (BM / 8);
+            const int g = o0 + 4 * u2;
+            const size_t wrow = (size_t)tap * d.w_tap_stride + (size_t)(kc + kk) * d.ldw;
+            if (g < a.H) {
+                ra[0] = *reinterpret_cast<const f32x4*>(d.w + wrow + g);
+                ra[1] = *reinterpret_cast<const f32x4*>(d.w + wrow + a.H + g);
+            } else {
+                ra[0] = f32x4{0, 0, 0, 0};
+                ra[1] = f32x4{0, 0, 0, 0};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int idx = tid + i * 256;
+                const int kk = idx / (BM / 4), u = idx % (BM / 4);
+                const int o = o0 + 4 * u;
+                const size_t wrow = (size_t)tap * d.w_tap_stride + (size_t)(kc + kk) * d.ldw;
+                ra[i] = (o < d.M) ? *reinterpret_cast<const f32x4*>(d.w + wrow + o)
+                                  : f32x4{0, 0, 0, 0};
+            }
+        }
+        // ---- activations (the dilated / strided window of this tap)
+        const int shift = d.tap_shift[tap];
+        const float* xb;
+        int cbase;
+        if (kc < d.C0) {
+            xb = d.x0 + (size_t)b * d.C0 * d.T_in;
+            cbase = kc;
+        } else {
+            xb = d.x1 + (size_t)b * d.C1 * d.T_in;
+            cbase = kc - d.C0;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int idx = tid + i * 256;
+            const int kk = idx / (BN / 4), u = idx % (BN / 4);
+            const float* row = xb + (size_t)(cbase + kk) * d.T_in;
+            const int ti = d.in_stride * (t0 + 4 * u) + shift;
+            rb[i] = load_x4(row, ti, d.T_in, d.in_stride, d.in_relu);
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* Ab = As + buf * BK * BM;
+        float* Bb = Bs + buf * BK * BN;
+        if constexpr (GATE) {
+            const int kk = tid / (BM / 8), u2 = tid % (BM / 8);
+            float* p = Ab + kk * BM + 8 * u2;
+            *reinterpret_cast<f32x4*>(p) = f32x4{ra[0][0], ra[1][0], ra[0][1], ra[1][1]};
+            *reinterpret_cast<f32x4*>(p + 4) = f32x4{ra[0][2], ra[1][2], ra[0][3], ra[1][3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int idx = tid + i * 256;
+                const int kk = idx / (BM / 4), u = idx % (BM / 4);
+                *reinterpret_cast<f32x4*>(Ab + kk * BM + 4 * u) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int idx = tid + i * 256;
+            const int kk = idx / (BN / 4), u = idx % (BN / 4);
+            *reinterpret_cast<f32x4*>(Bb + kk * BN + 4 * u) = rb[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int e = 0; e < MT; ++e)
+#pragma unroll
+        for (int f = 0; f < NT; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.0f;
+
+    int ld_tap = next_tap(-1), ld_kc = 0;
+    if (nsteps > 0) {
+        load_tiles(ld_tap, ld_kc);
+        store_tiles(0);
+        ld_kc += BK;
+        if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
+    }
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const bool more = (s + 1 < nsteps);
+        if (more) {
+            load_tiles(ld_tap, ld_kc);  // global loads in flight under the MFMAs below
+            ld_kc += BK;
+            if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
+        }
+        const float* Ab = As + buf * BK * BM + wm * (MT * 32) + MT * l31;
+        const float* Bb = Bs + buf * BK * BN + wn * (NT * 32) + NT * l31;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = 2 * ks + lhi;
+            float av[MT], bv[NT];
+            if constexpr (MT == 2) {
+                const f32x2 t = *reinterpret_cast<const f32x2*>(Ab + kk * BM);
+                av[0] = t[0]; av[1] = t[1];
+            } else {
+                av[0] = Ab[kk * BM];
+            }
+            if constexpr (NT == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(Bb + kk * BN);
+                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+            } else {
+                const f32x2 t = *reinterpret_cast<const f32x2*>(Bb + kk * BN);
+                bv[0] = t[0]; bv[1] = t[1];
+            }
+#pragma unroll
+            for (int e = 0; e < MT; ++e)
+#pragma unroll
+                for (int f = 0; f < NT; ++f)
+                    acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int tb = t0 + wn * (NT * 32) + NT * l31;  // first of this lane's NT output times
+    if (tb >= d.T_out) return;
+    const int Ts = d.T_store;
+    const int tstr = d.out_tstride, toff = d.out_toffset, vok = a.vec_ok;
+
+    int tz[NT];
+    if (d.cond_T > 0) {
+#pragma unroll
+        for (int f = 0; f < NT; ++f) tz[f] = min(tb + f, d.T_out - 1) / a.ratio;
+    }
+
+#pragma unroll
+    for (int rho = 0; rho < 16; ++rho) {
+        const int r = (rho & 3) + 8 * (rho >> 2) + 4 * lhi;  // row inside the 32x32 tile
+        if constexpr (EPI == VQW_EPI_GATE) {
+            const int g = o0 + wm * 32 + r;  // gated channel
+            if (g < a.H) {
+                const float bfv = d.bias ? d.bias[g] : 0.0f;
+                const float bgv = d.bias ? d.bias[a.H + g] : 0.0f;
+                float og[NT], ot[NT], os[NT];
+#pragma unroll
+                for (int f = 0; f < NT; ++f) {
+                    float vf = acc[0][f][rho] + bfv, vg = acc[1][f][rho] + bgv;
+                    if (d.cond_T > 0) {
+                        const float* cb = d.cond + (size_t)b * d.cond_bstride;
+                        vf += cb[(size_t)g * d.cond_T + tz[f]];
+                        vg += cb[(size_t)(a.H + g) * d.cond_T + tz[f]];
+                    }
+                    ot[f] = tanh_f(vf);
+                    os[f] = sigmoid_f(vg);
+                    og[f] = ot[f] * os[f];
+                }
+                const size_t ro = ((size_t)b * a.H + g) * Ts;
+                store_row<NT>(d.out0 + ro, tb, d.T_out, tstr, toff, vok, og);
+                if (d.save0) store_row<NT>(d.save0 + ro, tb, d.T_out, tstr, toff, vok, ot);
+                if (d.save1) store_row<NT>(d.save1 + ro, tb, d.T_out, tstr, toff, vok, os);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < MT; ++e) {
+                const int row = o0 + wm * (MT * 32) + MT * r + e;
+                if (row >= d.M) continue;
+                float v[NT];
+#pragma unroll
+                for (int f = 0; f < NT; ++f) v[f] = acc[e][f][rho];
+
+                if constexpr (EPI == VQW_EPI_STORE) {
+                    const float bv = d.bias ? d.bias[row] : 0.0f;
+#pragma unroll
+                    for (int f = 0; f < NT; ++f) {
+                        v[f] += bv;
+                        if (d.cond_T > 0)
+                            v[f] += d.cond[(size_t)b * d.cond_bstride + (size_t)row * d.cond_T + tz[f]];
+                        if (d.out_relu) v[f] = fmaxf(v[f], 0.0f);
+                    }
+                    if (d.save0)
+                        store_row<NT>(d.save0 + ((size_t)b * d.M + row) * Ts, tb, d.T_out, tstr,
+                                      toff, vok, v);
+                    if (d.scale) {
+                        const float sc = d.scale[row], sh = d.shift[row];
+#pragma unroll
+                        for (int f = 0; f < NT; ++f) v[f] = sc * v[f] + sh;
+                    }
+                    float* dst = (row < d.M0)
+                                     ? d.out0 + ((size_t)b * d.M0 + row) * Ts
+                                     : d.out1 + ((size_t)b * (d.M - d.M0) + (row - d.M0)) * Ts;
+                    store_row<NT>(dst, tb, d.T_out, tstr, toff, vok, v);
+                } else if constexpr (EPI == VQW_EPI_ACCUM_SPLIT) {
+                    const float bv = d.bias ? d.bias[row] : 0.0f;
+                    float old[NT];
+                    float* dst;
+                    if (row < d.M0) {
+                        dst = d.out0 + ((size_t)b * d.M0 + row) * Ts;
+                        load_row<NT>(dst, tb, d.T_out, tstr, toff, vok, old);
+                    } else {
+                        const size_t ro = ((size_t)b * (d.M - d.M0) + (row - d.M0)) * Ts;
+                        dst = d.out1 + ro;
+                        load_row<NT>(d.aux1 + ro, tb, d.T_out, tstr, toff, vok, old);
+                    }
+#pragma unroll
+                    for (int f = 0; f < NT; ++f) v[f] = old[f] + (v[f] + bv);
+                    store_row<NT>(dst, tb, d.T_out, tstr, toff, vok, v);
+                } else if constexpr (EPI == VQW_EPI_GATE_BWD) {
+                    const size_t ri = ((size_t)b * a.H + row) * Ts;
+                    float th[NT], sg[NT], o1[NT], o2[NT];
+                    load_row<NT>(d.aux0 + ri, tb, d.T_out, tstr, toff, vok, th);
+                    load_row<NT>(d.aux1 + ri, tb, d.T_out, tstr, toff, vok, sg);
+#pragma unroll
+                    for (int f = 0; f < NT; ++f) {
+                        o1[f] = v[f] * sg[f] * (1.0f - th[f] * th[f]);
+                        o2[f] = v[f] * th[f] * sg[f] * (1.0f - sg[f]);
+                    }
+                    store_row<NT>(d.out0 + ((size_t)b * 2 * a.H + row) * Ts, tb, d.T_out, tstr,
+                                  toff, vok, o1);
+                    store_row<NT>(d.out0 + ((size_t)b * 2 * a.H + a.H + row) * Ts, tb, d.T_out,
+                                  tstr, toff, vok, o2);
+                } else {  // VQW_EPI_MASK
+                    const size_t ro = ((size_t)b * d.M + row) * Ts;
+                    float m[NT];
+                    load_row<NT>(d.aux0 + ro, tb, d.T_out, tstr, toff, vok, m);
+                    const float sc = d.scale ? d.scale[row] : 1.0f;
+#pragma unroll
+                    for (int f = 0; f < NT; ++f) v[f] = (m[f] > 0.0f) ? v[f] * sc : 0.0f;
+                    store_row<NT>(d.out0 + ro, tb, d.T_out, tstr, toff, vok, v);
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int NT>
+int launch_cfg(ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 64 * MT, BN = 64 * NT;
+    const vqw_conv_desc& d = a.d;
+    const bool gate = d.epilogue == VQW_EPI_GATE;
+    a.n_mt = gate ? vqw_cdiv(a.H, BM / 2) : vqw_cdiv(d.M, BM);
+    a.n_nt = vqw_cdiv(d.T_out, BN);
+    a.nwg = a.n_mt * a.n_nt * d.B;
+    dim3 grid(a.nwg), block(256);
+    switch (d.epilogue) {
+        case VQW_EPI_STORE:
+            hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, VQW_EPI_STORE>), grid, block, 0, st, a);
+            break;
+        case VQW_EPI_ACCUM_SPLIT:
+            hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, VQW_EPI_ACCUM_SPLIT>), grid, block, 0, st, a);
+            break;
+        case VQW_EPI_GATE:
+            if constexpr (MT == 2) {
+                hipLaunchKernelGGL((conv_gemm_kernel<2, NT, VQW_EPI_GATE>), grid, block, 0, st, a);
+            } else {
+                return vqw_set_error("vqw_conv_gemm: GATE needs an MT=2 tile");
+            }
+            break;
+        case VQW_EPI_GATE_BWD:
+            hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, VQW_EPI_GATE_BWD>), grid, block, 0, st, a);
+            break;
+        case VQW_EPI_MASK:
+            hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, VQW_EPI_MASK>), grid, block, 0, st, a);
+            break;
+        default:
+            return vqw_set_error("vqw_conv_gemm: unknown epilogue %d", d.epilogue);
+    }
+    VQW_LAUNCH_CHECK("vqw_conv_gemm");
+    return 0;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
+    VQW_CHECK(dp != nullptr, "vqw_conv_gemm: null descriptor");
+    ConvArgs a;
+    a.d = *dp;
+    vqw_conv_desc& d = a.d;
+    VQW_CHECK(d.B > 0 && d.T_out > 0 && d.T_in > 0 && d.M > 0, "vqw_conv_gemm: bad shape B=%d T_out=%d T_in=%d M=%d", d.B, d.T_out, d.T_in, d.M);
+    VQW_CHECK(d.C0 > 0 && d.C0 % BK == 0 && d.C1 >= 0 && d.C1 % BK == 0, "vqw_conv_gemm: C0=%d / C1=%d must be multiples of %d", d.C0, d.C1, BK);
+    VQW_CHECK(d.ntaps >= 1 && d.ntaps <= VQW_MAX_TAPS, "vqw_conv_gemm: ntaps=%d out of range", d.ntaps);
+    VQW_CHECK(d.in_stride == 1 || d.in_stride == 2, "vqw_conv_gemm: in_stride must be 1 or 2");
+    VQW_CHECK(d.M % 4 == 0 && d.ldw % 4 == 0 && d.ldw >= d.M, "vqw_conv_gemm: M=%d ldw=%d must be multiples of 4, ldw>=M", d.M, d.ldw);
+    VQW_CHECK(d.x0 && d.w && d.out0, "vqw_conv_gemm: x0/w/out0 must not be null");
+    VQW_CHECK(d.C1 == 0 || d.x1, "vqw_conv_gemm: C1>0 needs x1");
+    VQW_CHECK(aligned16(d.w), "vqw_conv_gemm: w must be 16-byte aligned");
+    if (d.out_tstride <= 0) d.out_tstride = 1;
+    if (d.w_tap_stride <= 0) d.w_tap_stride = (int64_t)(d.C0 + d.C1) * d.ldw;
+    if (d.T_store <= 0) d.T_store = d.out_tstride * d.T_out;
+    a.H = 0;
+    a.ratio = 1;
+    if (d.cond_T > 0) {
+        VQW_CHECK(d.cond != nullptr, "vqw_conv_gemm: cond_T>0 needs cond");
+        VQW_CHECK(d.T_out % d.cond_T == 0, "vqw_conv_gemm: T_out=%d not a multiple of cond_T=%d", d.T_out, d.cond_T);
+        a.ratio = d.T_out / d.cond_T;
+    }
+    switch (d.epilogue) {
+        case VQW_EPI_GATE:
+            VQW_CHECK(d.M % 8 == 0, "vqw_conv_gemm: GATE needs M=2H with H%%4==0");
+            a.H = d.M / 2;
+            break;
+        case VQW_EPI_GATE_BWD:
+            VQW_CHECK(d.aux0 && d.aux1, "vqw_conv_gemm: GATE_BWD needs aux0 (tanh) and aux1 (sigmoid)");
+            a.H = d.M;
+            break;
+        case VQW_EPI_MASK:
+            VQW_CHECK(d.aux0, "vqw_conv_gemm: MASK needs aux0");
+            break;
+        case VQW_EPI_ACCUM_SPLIT:
+            if (d.M0 < 0) d.M0 = 0;
+            if (d.M0 > d.M) d.M0 = d.M;
+            VQW_CHECK(d.M0 == d.M || (d.out1 && d.aux1), "vqw_conv_gemm: ACCUM_SPLIT rows >= M0 need out1 and aux1");
+            break;
+        case VQW_EPI_STORE:
+            if (d.M0 <= 0 || d.M0 > d.M || !d.out1) d.M0 = d.M;
+            VQW_CHECK(!d.scale || d.shift, "vqw_conv_gemm: scale needs shift");
+            break;
+        default:
+            return vqw_set_error("vqw_conv_gemm: unknown epilogue %d", d.epilogue);
+    }
+    a.vec_ok = (d.out_tstride == 1 && d.out_toffset == 0 && d.T_store % 4 == 0 &&
+                aligned16(d.out0) && (!d.out1 || aligned16(d.out1)) &&
+                (!d.aux0 || aligned16(d.aux0)) && (!d.aux1 || aligned16(d.aux1)) &&
+                (!d.save0 || aligned16(d.save0)) && (!d.save1 || aligned16(d.save1)))
+                   ? 1 : 0;
+
+    hipStream_t st = static_cast<hipStream_t>(s);
+    int tile = d.tile;
+    if (tile == 0) {
+        const int rows = (d.epilogue == VQW_EPI_GATE) ? d.M : d.M;
+        const int mt = (rows <= 64 && d.epilogue != VQW_EPI_GATE) ? 1 : 2;
+        // wide time tiles when there is enough work to fill the chip with them
+        const long blocks_wide = (long)vqw_cdiv(rows, 64 * mt) * vqw_cdiv(d.T_out, 256) * d.B;
+        const int ntile = (d.T_out >= 256 && blocks_wide >= 512) ? 4 : 2;
+        tile = 10 * mt + ntile;
+    }
+    switch (tile) {
+        case 24: return launch_cfg<2, 4>(a, st);
+        case 22: return launch_cfg<2, 2>(a, st);
+        case 14: return launch_cfg<1, 4>(a, st);
+        case 12: return launch_cfg<1, 2>(a, st);
+        default: return vqw_set_error("vqw_conv_gemm: unsupported tile %d", tile);
+    }
+}

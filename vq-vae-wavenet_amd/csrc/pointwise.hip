@@ -1,0 +1,423 @@
+// HBM-bound kernels of the hot path for gfx950: mu-law companding, Cin==1 convs, row
+// reductions, transposes, softmax cross-entropy and the fused Adam+EMA step.
+// Reference call sites are cited per kernel; numerics follow SURVEY.md Appendix A.
+#include "mu_law_table.h"
+#include "vqw_common.h"
+
+namespace {
+
+__device__ __constant__ unsigned int VQW_MU_LAW_THR_BITS_DEV[255] = VQW_MU_LAW_THR_BITS_LIST;
+
+// ----------------------------------------------------------------------------- mu-law
+__device__ __forceinline__ float mu_encode_f(float x) {
+    // mu_law_ops.py:6-8
+    x = fminf(fmaxf(x, -1.0f), 1.0f);
+    const float s = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    return s * log1pf(255.0f * fabsf(x)) / 5.5451774444795623f;
+}
+
+// label(x) = #{thr <= clip(x)}: compares only => bit-exact vs the fp32 formula
+// (mu_law_ops.py:11); table from tools/gen_mu_law_table.py.
+__device__ __forceinline__ int mu_encode_i(float x, const float* thr) {
+    x = fminf(fmaxf(x, -1.0f), 1.0f);
+    int lo = 0, hi = 255;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const bool ge = (lo < hi) && (thr[mid] <= x);
+        const bool lt = (lo < hi) && !(thr[mid] <= x);
+        lo = ge ? mid + 1 : lo;
+        hi = lt ? mid : hi;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void load_thr(float* thr) {
+    for (int i = threadIdx.x; i < 255; i += blockDim.x) thr[i] = __uint_as_float(VQW_MU_LAW_THR_BITS_DEV[i]);
+    __syncthreads();
+}
+
+__global__ void mu_encode_f32_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = mu_encode_f(x[i]);
+}
+
+__global__ void mu_encode_i32_kernel(const float* __restrict__ x, int32_t* __restrict__ y, size_t n) {
+    __shared__ float thr[256];
+    load_thr(thr);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = mu_encode_i(x[i], thr);
+}
+
+__global__ void mu_decode_f32_kernel(const float* __restrict__ idx, float* __restrict__ x, size_t n) {
+    // mu_law_ops.py:26-31
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float y = 2.0f * idx[i] / 255.0f - 1.0f;
+        const float s = (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f);
+        x[i] = s * (powf(256.0f, fabsf(y)) - 1.0f) / 255.0f;
+    }
+}
+
+// wavenet.py:33-37: labels from x, decoder input from shift_right(x) (wavenet_ops.py:9-14)
+__global__ void wavenet_inputs_kernel(const float* __restrict__ x, float* __restrict__ inputs,
+                                      int32_t* __restrict__ labels, int B, int T) {
+    __shared__ float thr[256];
+    load_thr(thr);
+    const size_t n = (size_t)B * T;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const float v = x[i];
+        if (labels) labels[i] = mu_encode_i(v, thr);
+        if (inputs) inputs[i] = (t == 0) ? 0.0f : mu_encode_f(x[i - 1]);
+    }
+}
+
+// ----------------------------------------------------------------------------- Cin == 1 convs
+// wavenet.py:42-44 (preprocess, causal k=32) and encoder.py:15 layer 1 (k=5, stride 2, SAME).
+template <int KMAX>
+__global__ void conv_cin1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                     const float* __restrict__ bias, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ out,
+                                     float* __restrict__ save_r, int T_in, int T_out, int F, int k,
+                                     int stride, int offset, int relu) {
+    const int f = blockIdx.y, b = blockIdx.z;
+    const int t0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (t0 >= T_out) return;
+    const float* xr = x + (size_t)b * T_in;
+    float acc[4];
+    const float bv = bias ? bias[f] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = bv;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        if (j < k) {
+            const float wv = w[(size_t)j * F + f];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ti = stride * (t0 + e) + j + offset;
+                const float xv = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
+                acc[e] = fmaf(wv, xv, acc[e]);
+            }
+        }
+    }
+    const size_t ro = ((size_t)b * F + f) * T_out;
+    float r[4], y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = relu ? fmaxf(acc[e], 0.0f) : acc[e];
+        y[e] = scale ? scale[f] * r[e] + shift[f] : r[e];
+    }
+    if (t0 + 3 < T_out && (T_out & 3) == 0) {
+        *reinterpret_cast<f32x4*>(out + ro + t0) = f32x4{y[0], y[1], y[2], y[3]};
+        if (save_r) *reinterpret_cast<f32x4*>(save_r + ro + t0) = f32x4{r[0], r[1], r[2], r[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (t0 + e < T_out) {
+                out[ro + t0 + e] = y[e];
+                if (save_r) save_r[ro + t0 + e] = r[e];
+            }
+    }
+}
+
+template <int KMAX>
+__global__ void conv_cin1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                       float* __restrict__ dw, int T_in, int T_out, int F, int k,
+                                       int stride, int offset) {
+    __shared__ float red[4][KMAX];
+    const int f = blockIdx.y, b = blockIdx.z;
+    const int t0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const float* xr = x + (size_t)b * T_in;
+    const float* dr = dout + ((size_t)b * F + f) * T_out;
+    float acc[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int t = t0 + e;
+        const float dv = (t < T_out) ? dr[t] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < k) {
+                const int ti = stride * t + j + offset;
+                const float xv = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
+                acc[j] = fmaf(xv, dv, acc[j]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        float v = acc[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wid][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < k) {
+        const int j = threadIdx.x;
+        unsafeAtomicAdd(dw + (size_t)j * F + f, red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+    }
+}
+
+// ----------------------------------------------------------------------------- row sums
+// One wave per (b, c) row.  LPS = lanes per segment (seg/4); 0 = no segment output.
+__global__ void rowsum_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                              float* __restrict__ seg_out, float* __restrict__ total, float alpha,
+                              int rows, int C, int T, int lps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * T;
+    const float* yr = y ? y + (size_t)row * T : nullptr;
+    const int nq = T >> 2;  // float4 per row
+    const int nseg = lps ? nq / lps : 0;
+    float tot = 0.0f;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int q = q0 + lane;
+        float s = 0.0f;
+        if (q < nq) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+            if (yr) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(yr + 4 * q);
+                v = v * u;
+            }
+            s = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        tot += s;
+        if (lps) {
+            float g = s;
+            for (int o = lps >> 1; o > 0; o >>= 1) g += __shfl_xor(g, o);
+            if ((lane % lps) == 0 && q < nq) seg_out[(size_t)row * nseg + q / lps] = g;
+        }
+    }
+    if (total) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (lane == 0) unsafeAtomicAdd(total + (row % C), alpha * tot);
+    }
+}
+
+// ----------------------------------------------------------------------------- transpose
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                 int cols) {
+    __shared__ float tile[32][33];
+    const size_t boff = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[boff + (size_t)r * cols + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) dst[boff + (size_t)c * rows + r] = tile[tx][i];
+    }
+}
+
+// ----------------------------------------------------------------------------- softmax CE
+// model.py:91-94.  Block = 4 waves x 64 consecutive time steps; wave w owns channels
+// [w*Q/4, (w+1)*Q/4): every load is a 256-byte row segment.
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
+                                                           const int32_t* __restrict__ labels,
+                                                           float* __restrict__ dlogits,
+                                                           float* __restrict__ probs,
+                                                           float* __restrict__ loss_sum,
+                                                           float grad_scale, int Q, int T) {
+    __shared__ float sm[4][64], ss[4][64], sl[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ntile = (T + 63) / 64;
+    const int b = blockIdx.x / ntile;
+    const int t = (blockIdx.x % ntile) * 64 + lane;
+    const bool ok = t < T;
+    const int qn = Q / 4, q0 = w * qn;
+    const float* lp = logits + ((size_t)b * Q + q0) * T + t;
+    const int lab = ok ? labels[(size_t)b * T + t] : 0;
+    float m = -INFINITY, s = 0.0f, xl = 0.0f;
+    if (ok) {
+        for (int q = 0; q < qn; ++q) {
+            const float v = lp[(size_t)q * T];
+            if (q0 + q == lab) xl = v;
+            const float mn = fmaxf(m, v);
+            s = s * __expf(m - mn) + __expf(v - mn);
+            m = mn;
+        }
+    }
+    sm[w][lane] = m; ss[w][lane] = s; sl[w][lane] = xl;
+    __syncthreads();
+    float M = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
+    float S = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S += ss[i][lane] * __expf(sm[i][lane] - M);
+    const float XL = (sl[0][lane] + sl[1][lane]) + (sl[2][lane] + sl[3][lane]);  // only one is non-zero
+    if (w == 0) {
+        float loss = ok ? (logf(S) + M - XL) : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+        if (lane == 0) unsafeAtomicAdd(loss_sum, loss);
+    }
+    if (ok && (dlogits || probs)) {
+        const float inv = 1.0f / S;
+        const size_t base = ((size_t)b * Q + q0) * T + t;
+        for (int q = 0; q < qn; ++q) {
+            const float p = __expf(lp[(size_t)q * T] - M) * inv;
+            if (probs) probs[base + (size_t)q * T] = p;
+            if (dlogits) dlogits[base + (size_t)q * T] = (p - ((q0 + q == lab) ? 1.0f : 0.0f)) * grad_scale;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- Adam + EMA
+// model.py:116-128 with TF-1.x epsilon placement.
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                float* __restrict__ m, float* __restrict__ v,
+                                float* __restrict__ ema, size_t n4, size_t n, float lr_t, float b1,
+                                float b2, float eps, float decay, float gs) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 P = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 G = reinterpret_cast<const f32x4*>(g)[i] * gs;
+        f32x4 Mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 Vv = reinterpret_cast<f32x4*>(v)[i];
+        f32x4 E = reinterpret_cast<f32x4*>(ema)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Mv[e] = b1 * Mv[e] + (1.0f - b1) * G[e];
+            Vv[e] = b2 * Vv[e] + (1.0f - b2) * G[e] * G[e];
+            P[e] = P[e] - lr_t * Mv[e] / (sqrtf(Vv[e]) + eps);
+            E[e] = E[e] - (1.0f - decay) * (E[e] - P[e]);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = P;
+        reinterpret_cast<f32x4*>(m)[i] = Mv;
+        reinterpret_cast<f32x4*>(v)[i] = Vv;
+        reinterpret_cast<f32x4*>(ema)[i] = E;
+    }
+    // tail (n not a multiple of 4)
+    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float G = g[i] * gs;
+        const float M = b1 * m[i] + (1.0f - b1) * G;
+        const float V = b2 * v[i] + (1.0f - b2) * G * G;
+        const float P = p[i] - lr_t * M / (sqrtf(V) + eps);
+        m[i] = M; v[i] = V; p[i] = P;
+        ema[i] = ema[i] - (1.0f - decay) * (ema[i] - P);
+    }
+}
+
+inline int grid_for(size_t n, int block) {
+    size_t g = (n + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" int vqw_mu_law_encode_f32(const float* x, float* y, size_t n, vqw_stream_t s) {
+    VQW_CHECK(x && y, "vqw_mu_law_encode_f32: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mu_encode_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, x, y, n);
+    VQW_LAUNCH_CHECK("vqw_mu_law_encode_f32");
+    return 0;
+}
+
+extern "C" int vqw_mu_law_encode_i32(const float* x, int32_t* y, size_t n, vqw_stream_t s) {
+    VQW_CHECK(x && y, "vqw_mu_law_encode_i32: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mu_encode_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, x, y, n);
+    VQW_LAUNCH_CHECK("vqw_mu_law_encode_i32");
+    return 0;
+}
+
+extern "C" int vqw_mu_law_decode_f32(const float* idx, float* x, size_t n, vqw_stream_t s) {
+    VQW_CHECK(idx && x, "vqw_mu_law_decode_f32: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mu_decode_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, idx, x, n);
+    VQW_LAUNCH_CHECK("vqw_mu_law_decode_f32");
+    return 0;
+}
+
+extern "C" int vqw_wavenet_inputs(const float* x, float* inputs, int32_t* labels, int B, int T, vqw_stream_t s) {
+    VQW_CHECK(x && (inputs || labels), "vqw_wavenet_inputs: null pointer");
+    VQW_CHECK(B > 0 && T > 0, "vqw_wavenet_inputs: bad shape");
+    hipLaunchKernelGGL(wavenet_inputs_kernel, dim3(grid_for((size_t)B * T, 256)), dim3(256), 0, (hipStream_t)s, x, inputs, labels, B, T);
+    VQW_LAUNCH_CHECK("vqw_wavenet_inputs");
+    return 0;
+}
+
+extern "C" int vqw_conv_cin1_fwd(const float* x, const float* w, const float* bias, const float* scale,
+                                 const float* shift, float* out, float* save_r, int B, int T_in,
+                                 int T_out, int F, int k, int stride, int offset, int relu, vqw_stream_t s) {
+    VQW_CHECK(x && w && out, "vqw_conv_cin1_fwd: null pointer");
+    VQW_CHECK(B > 0 && T_in > 0 && T_out > 0 && F > 0 && k >= 1 && k <= 32 && stride >= 1, "vqw_conv_cin1_fwd: bad shape (k<=32)");
+    VQW_CHECK(!scale || shift, "vqw_conv_cin1_fwd: scale needs shift");
+    dim3 grid(vqw_cdiv(vqw_cdiv(T_out, 4), 256), F, B);
+    if (k <= 8)
+        hipLaunchKernelGGL((conv_cin1_fwd_kernel<8>), grid, dim3(256), 0, (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
+    else
+        hipLaunchKernelGGL((conv_cin1_fwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
+    VQW_LAUNCH_CHECK("vqw_conv_cin1_fwd");
+    return 0;
+}
+
+extern "C" int vqw_conv_cin1_wgrad(const float* x, const float* dout, float* dw, int B, int T_in, int T_out,
+                                   int F, int k, int stride, int offset, vqw_stream_t s) {
+    VQW_CHECK(x && dout && dw, "vqw_conv_cin1_wgrad: null pointer");
+    VQW_CHECK(B > 0 && T_in > 0 && T_out > 0 && F > 0 && k >= 1 && k <= 32 && stride >= 1, "vqw_conv_cin1_wgrad: bad shape (k<=32)");
+    dim3 grid(vqw_cdiv(vqw_cdiv(T_out, 4), 256), F, B);
+    if (k <= 8)
+        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<8>), grid, dim3(256), 0, (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
+    else
+        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<32>), grid, dim3(256), 0, (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
+    VQW_LAUNCH_CHECK("vqw_conv_cin1_wgrad");
+    return 0;
+}
+
+extern "C" int vqw_rowsum(const float* x, const float* y, float* seg_out, float* total, float alpha, int B,
+                          int C, int T, int seg, vqw_stream_t s) {
+    VQW_CHECK(x && (seg_out || total), "vqw_rowsum: null pointer");
+    VQW_CHECK(B > 0 && C > 0 && T > 0 && T % 4 == 0, "vqw_rowsum: T=%d must be a positive multiple of 4", T);
+    VQW_CHECK((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (!y || (reinterpret_cast<uintptr_t>(y) & 15u) == 0), "vqw_rowsum: inputs must be 16-byte aligned");
+    int lps = 0;
+    if (seg_out) {
+        VQW_CHECK(seg >= 4 && seg % 4 == 0 && T % seg == 0, "vqw_rowsum: seg=%d must divide T and be a multiple of 4", seg);
+        lps = seg / 4;
+        VQW_CHECK(lps <= 64 && (lps & (lps - 1)) == 0, "vqw_rowsum: seg/4=%d must be a power of two <= 64", lps);
+    }
+    const int rows = B * C;
+    hipLaunchKernelGGL(rowsum_kernel, dim3(vqw_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, x, y, seg_out, total, alpha, rows, C, T, lps);
+    VQW_LAUNCH_CHECK("vqw_rowsum");
+    return 0;
+}
+
+extern "C" int vqw_transpose(const float* src, float* dst, int batch, int rows, int cols, vqw_stream_t s) {
+    VQW_CHECK(src && dst && batch > 0 && rows > 0 && cols > 0, "vqw_transpose: bad arguments");
+    dim3 grid(vqw_cdiv(cols, 32), vqw_cdiv(rows, 32), batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)s, src, dst, rows, cols);
+    VQW_LAUNCH_CHECK("vqw_transpose");
+    return 0;
+}
+
+extern "C" int vqw_softmax_xent(const float* logits, const int32_t* labels, float* dlogits, float* probs,
+                                float* loss_sum, float grad_scale, int B, int Q, int T, vqw_stream_t s) {
+    VQW_CHECK(logits && labels && loss_sum, "vqw_softmax_xent: null pointer");
+    VQW_CHECK(B > 0 && T > 0 && Q >= 4 && Q % 4 == 0, "vqw_softmax_xent: Q=%d must be a multiple of 4", Q);
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(B * vqw_cdiv(T, 64)), dim3(256), 0, (hipStream_t)s, logits, labels, dlogits, probs, loss_sum, grad_scale, Q, T);
+    VQW_LAUNCH_CHECK("vqw_softmax_xent");
+    return 0;
+}
+
+extern "C" int vqw_adam_ema_step(float* param, const float* grad, float* m, float* v, float* ema, size_t n,
+                                 float lr_t, float beta1, float beta2, float eps, float decay,
+                                 float grad_scale, vqw_stream_t s) {
+    VQW_CHECK(param && grad && m && v && ema, "vqw_adam_ema_step: null pointer");
+    if (n == 0) return 0;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
+                         reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                         reinterpret_cast<uintptr_t>(ema);
+    const size_t n4 = (al & 15u) ? 0 : n / 4;
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n4 ? n4 : n, 256)), dim3(256), 0, (hipStream_t)s, param, grad, m, v, ema, n4, n, lr_t, beta1, beta2, eps, decay, grad_scale);
+    VQW_LAUNCH_CHECK("vqw_adam_ema_step");
+    return 0;
+}

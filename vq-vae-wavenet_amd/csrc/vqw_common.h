@@ -1,0 +1,40 @@
+// Shared host/device helpers of libvqwave (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/vqwave.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 4 floats with only 4-byte alignment: lets the compiler emit one global_load_dwordx4 for
+// the time-shifted (dilated) activation windows, whose start is not 16-byte aligned.
+struct __attribute__((packed, aligned(4))) F4U {
+    float x, y, z, w;
+};
+
+int vqw_set_error(const char* fmt, ...);
+
+#define VQW_CHECK(cond, ...)                           \
+    do {                                               \
+        if (!(cond)) return vqw_set_error(__VA_ARGS__); \
+    } while (0)
+
+#define VQW_LAUNCH_CHECK(name)                                                     \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess)                                                      \
+            return vqw_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int vqw_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware block remap (bijective for any grid size): consecutive logical ids land on the
+// same XCD so that neighbouring tiles (which share an operand panel) share one L2.
+__device__ __forceinline__ int vqw_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,236 @@
+"""Typed Python front end of the C ABI on (batch, channel, time) torch tensors.
+
+Every function validates operand sizes on the host before launching (a mis-sized operand
+would otherwise fault on the GPU) and then calls libvqwave; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import EPI_ACCUM_SPLIT, EPI_GATE, EPI_GATE_BWD, EPI_MASK, EPI_STORE  # noqa: F401
+
+
+def _need(t, n, what):
+    if t is None:
+        raise ValueError('%s is required' % what)
+    if t.dtype != torch.float32:
+        raise ValueError('%s must be float32, got %s' % (what, t.dtype))
+    if t.numel() < n:
+        raise ValueError('%s has %d elements, kernel needs %d' % (what, t.numel(), n))
+    L.require_cuda(t)
+
+
+def conv_gemm(*, x0, w, out0, B, T_in, T_out, M, C0, taps, x1=None, C1=0, in_stride=1, ldw=None,
+              in_relu=False, epilogue=EPI_STORE, out_relu=False, M0=0, out_tstride=1, out_toffset=0,
+              T_store=0, cond=None, cond_T=0, cond_bstride=0, w_tap_stride=0, bias=None, scale=None,
+              shift=None, aux0=None, aux1=None, out1=None, save0=None, save1=None, tile=0):
+    """vqw_conv_gemm (include/vqwave.h).  `taps` = list of input shifts per tap."""
+    ldw = M if ldw is None else ldw
+    Ts = T_store if T_store > 0 else out_tstride * T_out
+    ntaps = len(taps)
+    wts = w_tap_stride if w_tap_stride > 0 else (C0 + C1) * ldw
+    _need(x0, B * C0 * T_in, 'x0')
+    if C1:
+        _need(x1, B * C1 * T_in, 'x1')
+    _need(w, (ntaps - 1) * wts + (C0 + C1 - 1) * ldw + M, 'w')
+    H = M // 2 if epilogue == EPI_GATE else M
+    if epilogue == EPI_GATE:
+        _need(out0, B * H * Ts, 'out0')
+        for t, nm in ((save0, 'save0'), (save1, 'save1')):
+            if t is not None:
+                _need(t, B * H * Ts, nm)
+        if bias is not None:
+            _need(bias, M, 'bias')
+    elif epilogue == EPI_GATE_BWD:
+        _need(out0, B * 2 * M * Ts, 'out0')
+        _need(aux0, B * M * Ts, 'aux0')
+        _need(aux1, B * M * Ts, 'aux1')
+    elif epilogue == EPI_MASK:
+        _need(out0, B * M * Ts, 'out0')
+        _need(aux0, B * M * Ts, 'aux0')
+    elif epilogue == EPI_ACCUM_SPLIT:
+        m0 = min(max(M0, 0), M)
+        if m0:
+            _need(out0, B * m0 * Ts, 'out0')
+        if m0 < M:
+            _need(out1, B * (M - m0) * Ts, 'out1')
+            _need(aux1, B * (M - m0) * Ts, 'aux1')
+    else:
+        m0 = M0 if (0 < M0 <= M and out1 is not None) else M
+        _need(out0, B * m0 * Ts, 'out0')
+        if m0 < M:
+            _need(out1, B * (M - m0) * Ts, 'out1')
+        if save0 is not None:
+            _need(save0, B * M * Ts, 'save0')
+    if bias is not None and epilogue != EPI_GATE:
+        _need(bias, M, 'bias')
+    if scale is not None:
+        _need(scale, M, 'scale')
+        if epilogue == EPI_STORE:
+            _need(shift, M, 'shift')
+    if cond_T:
+        rows = M
+        bs = cond_bstride if cond_bstride else rows * cond_T
+        _need(cond, (B - 1) * bs + rows * cond_T, 'cond')
+        cond_bstride = bs
+    d = L.ConvDesc()
+    d.B, d.T_out, d.T_in, d.M, d.C0, d.C1 = B, T_out, T_in, M, C0, C1
+    d.ntaps, d.in_stride = ntaps, in_stride
+    for j, s in enumerate(taps):
+        d.tap_shift[j] = int(s)
+    d.ldw, d.in_relu, d.epilogue, d.out_relu, d.M0 = ldw, int(in_relu), epilogue, int(out_relu), M0
+    d.out_tstride, d.out_toffset, d.T_store = out_tstride, out_toffset, T_store
+    d.cond_T, d.tile, d.cond_bstride, d.w_tap_stride = cond_T, tile, cond_bstride, w_tap_stride
+    for name, t in (('x0', x0), ('x1', x1), ('w', w), ('bias', bias), ('cond', cond), ('scale', scale),
+                    ('shift', shift), ('aux0', aux0), ('aux1', aux1), ('out0', out0), ('out1', out1),
+                    ('save0', save0), ('save1', save1)):
+        setattr(d, name, None if t is None else t.data_ptr())
+    L.check(L.lib().vqw_conv_gemm(C.byref(d), L.stream()))
+
+
+def wgrad_gemm(*, p, q0, dw, B, T_q, T_p, Cp, Q0, taps, q1=None, Q1=0, p_stride=1, p_relu=False,
+               lddw=None, dw_tap_stride=None, splits=0):
+    """vqw_wgrad_gemm: dw[j][c][o] += sum_{b,t} p[b][c][p_stride*t+taps[j]] * q[b][o][t]."""
+    lddw = (Q0 + Q1) if lddw is None else lddw
+    dw_tap_stride = Cp * lddw if dw_tap_stride is None else dw_tap_stride
+    _need(p, B * Cp * T_p, 'p')
+    _need(q0, B * Q0 * T_q, 'q0')
+    if Q1:
+        _need(q1, B * Q1 * T_q, 'q1')
+    _need(dw, (len(taps) - 1) * dw_tap_stride + (Cp - 1) * lddw + Q0 + Q1, 'dw')
+    d = L.WgradDesc()
+    d.B, d.T_q, d.T_p, d.Cp, d.Q0, d.Q1 = B, T_q, T_p, Cp, Q0, Q1
+    d.ntaps, d.p_stride = len(taps), p_stride
+    for j, s in enumerate(taps):
+        d.tap_shift[j] = int(s)
+    d.p_relu, d.lddw, d.splits, d.dw_tap_stride = int(p_relu), lddw, splits, dw_tap_stride
+    d.p, d.q0, d.q1, d.dw = p.data_ptr(), q0.data_ptr(), (None if q1 is None else q1.data_ptr()), dw.data_ptr()
+    L.check(L.lib().vqw_wgrad_gemm(C.byref(d), L.stream()))
+
+
+def mu_law_encode_f32(x, out=None):
+    L.require_cuda(x)
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().vqw_mu_law_encode_f32(L.ptr(x), L.ptr(out), x.numel(), L.stream()))
+    return out
+
+
+def mu_law_encode_i32(x, out=None):
+    L.require_cuda(x)
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device) if out is None else out
+    L.check(L.lib().vqw_mu_law_encode_i32(L.ptr(x), L.ptr(out), x.numel(), L.stream()))
+    return out
+
+
+def mu_law_decode_f32(idx, out=None):
+    L.require_cuda(idx)
+    out = torch.empty_like(idx) if out is None else out
+    L.check(L.lib().vqw_mu_law_decode_f32(L.ptr(idx), L.ptr(out), idx.numel(), L.stream()))
+    return out
+
+
+def wavenet_inputs(x, inputs, labels):
+    """x [B][T] -> inputs f32 [B][T] (mu-law of shift_right), labels int32 [B][T]."""
+    B, T = x.shape
+    L.require_cuda(x, inputs, labels)
+    L.check(L.lib().vqw_wavenet_inputs(L.ptr(x), L.ptr(inputs), L.ptr(labels), B, T, L.stream()))
+
+
+def conv_cin1_fwd(x, w, bias, out, *, k, stride, offset, relu=False, scale=None, shift=None, save_r=None):
+    B, T_in = x.shape
+    _, F, T_out = out.shape
+    _need(w, k * F, 'w')
+    L.require_cuda(x, out, bias, scale, shift, save_r)
+    L.check(L.lib().vqw_conv_cin1_fwd(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(out),
+                                      L.ptr(save_r), B, T_in, T_out, F, k, stride, offset, int(relu), L.stream()))
+
+
+def conv_cin1_wgrad(x, dout, dw, *, k, stride, offset):
+    B, T_in = x.shape
+    _, F, T_out = dout.shape
+    _need(dw, k * F, 'dw')
+    L.require_cuda(x, dout)
+    L.check(L.lib().vqw_conv_cin1_wgrad(L.ptr(x), L.ptr(dout), L.ptr(dw), B, T_in, T_out, F, k, stride, offset,
+                                        L.stream()))
+
+
+def rowsum(x, *, y=None, seg_out=None, total=None, alpha=1.0, seg=0):
+    """x [B][C][T]: seg_out[b][c][t/seg] (optional), total[c] += alpha*sum (optional)."""
+    B, Cc, T = x.shape
+    L.require_cuda(x, y, seg_out, total)
+    if y is not None and y.numel() != x.numel():
+        raise ValueError('rowsum: y size mismatch')
+    if seg_out is not None:
+        _need(seg_out, B * Cc * (T // seg), 'seg_out')
+    if total is not None:
+        _need(total, Cc, 'total')
+    L.check(L.lib().vqw_rowsum(L.ptr(x), L.ptr(y), L.ptr(seg_out), L.ptr(total), float(alpha), B, Cc, T, seg,
+                               L.stream()))
+
+
+def transpose(src, dst, batch, rows, cols):
+    _need(src, batch * rows * cols, 'src')
+    _need(dst, batch * rows * cols, 'dst')
+    L.check(L.lib().vqw_transpose(L.ptr(src), L.ptr(dst), batch, rows, cols, L.stream()))
+
+
+def vq_nearest_fwd(z_e, emb, *, idx, e_k=None, zq=None, zq_bstride=0, mind=None):
+    B, D, Tz = z_e.shape
+    K = emb.shape[0]
+    L.require_cuda(z_e, emb, idx, e_k, zq, mind)
+    if idx.dtype != torch.int64 or idx.numel() < B * Tz:
+        raise ValueError('idx must be int64 [B][Tz]')
+    if e_k is not None:
+        _need(e_k, B * D * Tz, 'e_k')
+    if zq is not None:
+        zq_bstride = zq_bstride or D * Tz
+        _need(zq, (B - 1) * zq_bstride + D * Tz, 'zq')
+    L.check(L.lib().vqw_vq_nearest_fwd(L.ptr(z_e), L.ptr(emb), L.ptr(idx), L.ptr(e_k), L.ptr(zq), zq_bstride,
+                                       L.ptr(mind), B, D, Tz, K, L.stream()))
+
+
+def vq_nearest_bwd(z_e, e_k, idx, *, dzq, dzq_bstride, dz_e, demb, cscale, escale, K):
+    B, D, Tz = z_e.shape
+    L.require_cuda(z_e, e_k, idx, dzq, dz_e, demb)
+    if dzq is not None:
+        _need(dzq, (B - 1) * dzq_bstride + D * Tz, 'dzq')
+    if demb is not None:
+        _need(demb, K * D, 'demb')
+    L.check(L.lib().vqw_vq_nearest_bwd(L.ptr(z_e), L.ptr(e_k), L.ptr(idx), L.ptr(dzq), dzq_bstride, L.ptr(dz_e),
+                                       L.ptr(demb), float(cscale), float(escale), B, D, Tz, K, L.stream()))
+
+
+def speaker_tile_fwd(table, spk, cond, *, cond_bstride, row0, Cs, Tz):
+    B = spk.numel()
+    L.require_cuda(table, spk, cond)
+    _need(cond, (B - 1) * cond_bstride + (row0 + Cs) * Tz, 'cond')
+    L.check(L.lib().vqw_speaker_tile_fwd(L.ptr(table), L.ptr(spk), L.ptr(cond), cond_bstride, row0, B, Cs, Tz,
+                                         L.stream()))
+
+
+def speaker_tile_bwd(dcond, spk, dtable, *, dcond_bstride, row0, Cs, Tz):
+    B = spk.numel()
+    L.require_cuda(dcond, spk, dtable)
+    _need(dcond, (B - 1) * dcond_bstride + (row0 + Cs) * Tz, 'dcond')
+    L.check(L.lib().vqw_speaker_tile_bwd(L.ptr(dcond), dcond_bstride, row0, L.ptr(spk), L.ptr(dtable), B, Cs, Tz,
+                                         L.stream()))
+
+
+def softmax_xent(logits, labels, *, loss_sum, dlogits=None, probs=None, grad_scale=1.0):
+    B, Q, T = logits.shape
+    L.require_cuda(logits, labels, loss_sum, dlogits, probs)
+    if labels.dtype != torch.int32 or labels.numel() != B * T:
+        raise ValueError('labels must be int32 [B][T]')
+    L.check(L.lib().vqw_softmax_xent(L.ptr(logits), L.ptr(labels), L.ptr(dlogits), L.ptr(probs), L.ptr(loss_sum),
+                                     float(grad_scale), B, Q, T, L.stream()))
+
+
+def adam_ema_step(param, grad, m, v, ema, *, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, decay=0.999,
+                  grad_scale=1.0):
+    n = param.numel()
+    for t, nm in ((grad, 'grad'), (m, 'm'), (v, 'v'), (ema, 'ema')):
+        _need(t, n, nm)
+    L.check(L.lib().vqw_adam_ema_step(L.ptr(param), L.ptr(grad), L.ptr(m), L.ptr(v), L.ptr(ema), n, float(lr_t),
+                                      float(beta1), float(beta2), float(eps), float(decay), float(grad_scale),
+                                      L.stream()))
