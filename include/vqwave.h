@@ -166,6 +166,11 @@ int vqw_conv_cin1_wgrad(const float* x, const float* dout, float* dw, int B, int
 int vqw_rowsum(const float* x, const float* y, float* seg_out, float* total, float alpha,
                int B, int C, int T, int seg, vqw_stream_t s);
 
+/* Backward of relu -> BatchNorm(inference affine) (encoder.py:19-20):
+ *   dz[b][c][t] = dx[b][c][t] * scale[c] * (r ? (r[b][c][t] > 0) : 1);  dz may alias dx.    */
+int vqw_bn_relu_bwd(const float* dx, const float* r, const float* scale, float* dz, int B,
+                    int C, int T, vqw_stream_t s);
+
 /* dst[b][c][r] = src[b][r][c]  (batched 2-D transpose; per-tap kernel transposes) */
 int vqw_transpose(const float* src, float* dst, int batch, int rows, int cols,
                   vqw_stream_t s);

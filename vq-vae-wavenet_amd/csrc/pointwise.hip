@@ -198,6 +198,17 @@ __global__ void rowsum_kernel(const float* __restrict__ x, const float* __restri
     }
 }
 
+// ----------------------------------------------------------------------------- relu/BN backward
+__global__ void bn_relu_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ r,
+                                   const float* __restrict__ scale, float* __restrict__ dz, int C, int T,
+                                   size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / T) % C);
+        const float v = dx[i] * scale[c];
+        dz[i] = (!r || r[i] > 0.0f) ? v : 0.0f;
+    }
+}
+
 // ----------------------------------------------------------------------------- transpose
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
                                  int cols) {
@@ -315,24 +326,24 @@ inline int grid_for(size_t n, int block) {
 
 // ============================================================================ C ABI
 extern "C" int vqw_mu_law_encode_f32(const float* x, float* y, size_t n, vqw_stream_t s) {
-    VQW_CHECK(x && y, "vqw_mu_law_encode_f32: null pointer");
     if (n == 0) return 0;
+    VQW_CHECK(x && y, "vqw_mu_law_encode_f32: null pointer");
     hipLaunchKernelGGL(mu_encode_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, x, y, n);
     VQW_LAUNCH_CHECK("vqw_mu_law_encode_f32");
     return 0;
 }
 
 extern "C" int vqw_mu_law_encode_i32(const float* x, int32_t* y, size_t n, vqw_stream_t s) {
-    VQW_CHECK(x && y, "vqw_mu_law_encode_i32: null pointer");
     if (n == 0) return 0;
+    VQW_CHECK(x && y, "vqw_mu_law_encode_i32: null pointer");
     hipLaunchKernelGGL(mu_encode_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, x, y, n);
     VQW_LAUNCH_CHECK("vqw_mu_law_encode_i32");
     return 0;
 }
 
 extern "C" int vqw_mu_law_decode_f32(const float* idx, float* x, size_t n, vqw_stream_t s) {
-    VQW_CHECK(idx && x, "vqw_mu_law_decode_f32: null pointer");
     if (n == 0) return 0;
+    VQW_CHECK(idx && x, "vqw_mu_law_decode_f32: null pointer");
     hipLaunchKernelGGL(mu_decode_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, idx, x, n);
     VQW_LAUNCH_CHECK("vqw_mu_law_decode_f32");
     return 0;
@@ -388,6 +399,15 @@ extern "C" int vqw_rowsum(const float* x, const float* y, float* seg_out, float*
     const int rows = B * C;
     hipLaunchKernelGGL(rowsum_kernel, dim3(vqw_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, x, y, seg_out, total, alpha, rows, C, T, lps);
     VQW_LAUNCH_CHECK("vqw_rowsum");
+    return 0;
+}
+
+extern "C" int vqw_bn_relu_bwd(const float* dx, const float* r, const float* scale, float* dz, int B, int C,
+                               int T, vqw_stream_t s) {
+    VQW_CHECK(dx && scale && dz && B > 0 && C > 0 && T > 0, "vqw_bn_relu_bwd: bad arguments");
+    const size_t n = (size_t)B * C * T;
+    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, dx, r, scale, dz, C, T, n);
+    VQW_LAUNCH_CHECK("vqw_bn_relu_bwd");
     return 0;
 }
 

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                                                : d.q1 + ((size_t)b * d.Q1 + (o - d.Q0)) * d.T_q;
                 f32x4 v;
                 if (t + 3 < tend) {
-                    v = *reinterpret_cast<const f32x4*>(rowp + t);
+                    const F4U u = *reinterpret_cast<const F4U*>(rowp + t);  // rows need only 4-byte alignment
+                    v = {u.x, u.y, u.z, u.w};
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (t + e < tend) ? rowp[t + e] : 0.0f;
@@ -202,9 +203,6 @@ extern "C" int vqw_wgrad_gemm(const vqw_wgrad_desc* dp, vqw_stream_t s) {
     VQW_CHECK(d.ntaps >= 1 && d.ntaps <= VQW_MAX_TAPS, "vqw_wgrad_gemm: ntaps=%d out of range", d.ntaps);
     VQW_CHECK(d.p_stride == 1 || d.p_stride == 2, "vqw_wgrad_gemm: p_stride must be 1 or 2");
     VQW_CHECK(d.p && d.q0 && d.dw && (d.Q1 == 0 || d.q1), "vqw_wgrad_gemm: null pointer");
-    VQW_CHECK(d.T_q % 4 == 0 && (reinterpret_cast<uintptr_t>(d.q0) & 15u) == 0 &&
-                  (!d.q1 || (reinterpret_cast<uintptr_t>(d.q1) & 15u) == 0),
-              "vqw_wgrad_gemm: q rows must be 16-byte aligned (T_q %% 4 == 0)");
     VQW_CHECK(d.lddw >= d.Q0 + d.Q1, "vqw_wgrad_gemm: lddw too small");
     constexpr int BM = 128, BN = 128;
     a.n_ct = vqw_cdiv(d.Cp, BM);

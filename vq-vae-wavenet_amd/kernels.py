@@ -169,6 +169,16 @@ def rowsum(x, *, y=None, seg_out=None, total=None, alpha=1.0, seg=0):
                                L.stream()))
 
 
+def bn_relu_bwd(dx, r, scale, dz):
+    B, Cc, T = dx.shape
+    L.require_cuda(dx, r, scale, dz)
+    _need(scale, Cc, 'scale')
+    _need(dz, dx.numel(), 'dz')
+    if r is not None:
+        _need(r, dx.numel(), 'r')
+    L.check(L.lib().vqw_bn_relu_bwd(L.ptr(dx), L.ptr(r), L.ptr(scale), L.ptr(dz), B, Cc, T, L.stream()))
+
+
 def transpose(src, dst, batch, rows, cols):
     _need(src, batch * rows * cols, 'src')
     _need(dst, batch * rows * cols, 'dst')

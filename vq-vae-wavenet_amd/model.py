@@ -1,0 +1,518 @@
+"""VQ-VAE-WaveNet on MI355X: host-side mirror of the reference's model assembly.
+
+Mirrors model.py:7-159 (class VQVAE), Encoder/encoder.py:8-26 (Encoder_64),
+Decoder/decoder.py:12-62 (WavenetDecoder) and Decoder/WaveNet/wavenet.py:24-172 (Wavenet) of
+the reference.  The reference builds a TF graph and lets TF autodiff + the TF runtime do the
+work; here one training step is an explicit forward + backward sequence of libvqwave kernels
+on (batch, channel, time) fp32 tensors.  PyTorch only owns device memory and streams.
+
+Parameters live in ONE flat fp32 buffer (so gradients are one contiguous all-reduce payload
+and Adam+EMA is one kernel); `named_parameters()` exposes them under the reference's TF
+variable names and shapes.
+"""
+import json
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+
+BN_EPS = 1e-3  # Keras BatchNormalization default epsilon
+
+
+def load_configs(model_json='model_parameters.json', wavenet_json=None):
+    """Same two JSON files as the reference (train.py:54-61, wavenet.py:10-13)."""
+    with open(model_json) as f:
+        m = json.load(f)
+    with open(wavenet_json or m['wavenet_parameters']) as f:
+        w = json.load(f)
+    assert len(w['dilation_rates']) == w['num_cycles'] * w['num_cycle_layers']  # wavenet.py:13
+    return m, w
+
+
+def same_pads(n, k, s):
+    """TF 'SAME' padding (left, right) -- SURVEY.md Appendix A-4."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def layer_scope(i, num_cycle_layers):
+    return 'decoder/cycle_%d/layer_%d' % (1 + i // num_cycle_layers, 1 + i % num_cycle_layers)
+
+
+def _suffix(i):
+    return '' if i == 0 else '_%d' % i
+
+
+class VQVAE:
+    """model.py:7-159.  encoder '64' + VQ + speaker embedding + WaveNet decoder."""
+
+    def __init__(self, model_cfg, wavenet_cfg, num_speakers, device='cuda', seed=0):
+        if model_cfg.get('encoder', '64') != '64':
+            raise NotImplementedError('encoder %s not implemented' % model_cfg.get('encoder'))
+        self.m, self.w = model_cfg, wavenet_cfg
+        self.dev = torch.device(device)
+        self.S_spk = num_speakers
+        self.F = model_cfg.get('encoder_filters', 768)
+        self.D = model_cfg['latent_dim']
+        self.Kc = model_cfg['k']
+        self.Cs = model_cfg['speaker_embedding']
+        self.beta = float(model_cfg['beta'])
+        self.use_vq = bool(model_cfg.get('use_vq', True))
+        if not self.use_vq or self.Cs <= 0:
+            raise NotImplementedError('this build implements the default use_vq=true, speaker_embedding>0 path')
+        self.Cc = self.D + self.Cs
+        w = wavenet_cfg
+        self.dil = list(w['dilation_rates'])
+        self.L = len(self.dil)
+        self.ks = w['kernel_size']
+        self.R, self.S, self.Q = w['residual_filters'], w['skip_filters'], w['quantization_channels']
+        if w['dilation_filters'] != self.R or w['preprocess']['filters'] != self.R:
+            raise NotImplementedError('dilation_filters / preprocess filters must equal residual_filters '
+                                      '(the reference adds them: wavenet.py:73)')
+        self.pre_k = w['preprocess']['kernel_size']
+        self.Mall = self.L * 2 * self.R + self.S  # all local-condition projections side by side
+        self.receptive_field = sum(self.dil) * (self.ks - 1) + 1 + self.pre_k - 1  # wavenet.py:16-17
+        self.schedule = [(int(k), float(v)) for k, v in model_cfg['learning_rate_schedule'].items()]
+        self.global_step = 0
+        self._build_layout()
+        self._init_params(seed)
+        self._ws = {}
+        self.loss_buf = torch.zeros(4, device=self.dev)  # [CE sum, sum of min distances, -, -]
+
+    # ------------------------------------------------------------------ parameter layout
+    def _build_layout(self):
+        F, D, R, S, Q, L, ks, Cc = self.F, self.D, self.R, self.S, self.Q, self.L, self.ks, self.Cc
+        seg = OrderedDict()  # internal (grouped) tensors of the flat buffer
+        seg['speaker_embedding'] = (self.S_spk, self.Cs)
+        seg['enc_w0'] = (5, F)                 # conv1d/kernel [5,1,F]
+        seg['enc_w'] = (5, 5, F, F)            # conv1d_1..5/kernel
+        seg['enc_b'] = (6, F)
+        seg['enc_w6'] = (F, D)                 # conv1d_6/kernel [1,F,D]
+        seg['enc_b6'] = (D,)
+        seg['bn_gamma'] = (6 * F + D,)
+        seg['bn_beta'] = (6 * F + D,)
+        seg['embedding'] = (self.Kc, D)
+        seg['pre_w'] = (self.pre_k, R)
+        seg['pre_b'] = (R,)
+        seg['skip0_w'] = (R, S)
+        seg['skip0_b'] = (S,)
+        seg['gated_w'] = (L, ks, R, 2 * R)
+        seg['gated_b'] = (L, 2 * R)
+        seg['cond_w'] = (Cc, self.Mall)        # [layer0 | layer1 | ... | postprocess1]
+        seg['out_w'] = (L, R, S + R)           # skip | residual 1x1 kernels side by side
+        seg['out_b'] = (L, S + R)
+        seg['post1_w'] = (S, S)
+        seg['post1_b'] = (S,)
+        seg['post2_w'] = (S, Q)
+        seg['post2_b'] = (Q,)
+        off = 0
+        self.seg_off = {}
+        for n, shp in seg.items():
+            self.seg_off[n] = (off, shp)
+            off += (math.prod(shp) + 3) // 4 * 4  # keep every segment 16-byte aligned
+        self.n_flat = off
+        self.seg_shapes = seg
+
+    def _views(self, flat):
+        return {n: flat[o:o + math.prod(shp)].view(shp) for n, (o, shp) in self.seg_off.items()}
+
+    def _init_params(self, seed):
+        dev = self.dev
+        self.flat = torch.zeros(self.n_flat, device=dev)
+        self.grad = torch.zeros(self.n_flat, device=dev)
+        self.adam_m = torch.zeros(self.n_flat, device=dev)
+        self.adam_v = torch.zeros(self.n_flat, device=dev)
+        self.P = self._views(self.flat)
+        self.G = self._views(self.grad)
+        self.bn_mean = torch.zeros(6 * self.F + self.D, device=dev)   # moving stats (never updated:
+        self.bn_var = torch.ones(6 * self.F + self.D, device=dev)     #  SURVEY.md Appendix A-3)
+        g = torch.Generator().manual_seed(seed)
+
+        def uus(shape, fan, factor):   # tf.uniform_unit_scaling_initializer
+            lim = math.sqrt(3.0 / fan) * factor
+            return (torch.rand(shape, generator=g) * 2 - 1) * lim
+
+        def glorot(shape, k, cin, cout):  # Keras glorot_uniform
+            lim = math.sqrt(6.0 / (k * cin + k * cout))
+            return (torch.rand(shape, generator=g) * 2 - 1) * lim
+
+        F, D, R, S, Q, L, ks, Cc = self.F, self.D, self.R, self.S, self.Q, self.L, self.ks, self.Cc
+        P = self.P
+        P['speaker_embedding'].copy_(uus((self.S_spk, self.Cs), self.S_spk, 2.0))   # model.py:23-26
+        P['enc_w0'].copy_(glorot((5, F), 5, 1, F))
+        P['enc_w'].copy_(glorot((5, 5, F, F), 5, F, F))
+        P['enc_w6'].copy_(glorot((F, D), 1, F, D))
+        P['bn_gamma'].fill_(1.0)
+        P['embedding'].copy_(uus((self.Kc, D), self.Kc, 1.7))                       # model.py:47-49
+        P['pre_w'].copy_(uus((self.pre_k, R), self.pre_k, 1.0))                     # wavenet_ops.py:69
+        P['skip0_w'].copy_(uus((R, S), R, 1.0))
+        P['gated_w'].copy_(uus((L, ks, R, 2 * R), ks * R, 1.0))
+        P['cond_w'].copy_(uus((Cc, self.Mall), Cc, 1.0))
+        P['out_w'].copy_(uus((L, R, S + R), R, 1.0))
+        P['post1_w'].copy_(uus((S, S), S, 1.0))
+        P['post2_w'].copy_(uus((S, Q), S, 1.0))
+        self.ema = self.flat.clone()     # ExponentialMovingAverage shadows start at the variables
+        self.E = self._views(self.ema)
+        # scratch: per-tap transposed kernels for the input-gradient GEMMs
+        self.T = {
+            'gated_w': torch.empty(L, ks, 2 * R, R, device=dev),
+            'out_w': torch.empty(L, S + R, R, device=dev),
+            'post1_w': torch.empty(S, S, device=dev),
+            'post2_w': torch.empty(Q, S, device=dev),
+            'skip0_w': torch.empty(S, R, device=dev),
+            'cond_w': torch.empty(self.Mall, Cc, device=dev),
+            'enc_w': torch.empty(5, 5, F, F, device=dev),
+            'enc_w6': torch.empty(D, F, device=dev),
+        }
+
+    # ------------------------------------------------------------------ reference-name views
+    def _named(self, V, bn_stats=True):
+        """Reference TF variable name -> tensor (copy) with the reference shape."""
+        F, D, R, S, L = self.F, self.D, self.R, self.S, self.L
+        out = OrderedDict()
+        out['speaker_embedding'] = V['speaker_embedding']
+        out['encoder/conv1d/kernel'] = V['enc_w0'].reshape(5, 1, F)
+        for i in range(1, 6):
+            out['encoder/conv1d_%d/kernel' % i] = V['enc_w'][i - 1]
+        for i in range(6):
+            out['encoder/conv1d%s/bias' % _suffix(i)] = V['enc_b'][i]
+        out['encoder/conv1d_6/kernel'] = V['enc_w6'].reshape(1, F, D)
+        out['encoder/conv1d_6/bias'] = V['enc_b6']
+        for i in range(7):
+            n = F if i < 6 else D
+            sl = slice(i * F, i * F + n)
+            out['encoder/batch_normalization%s/gamma' % _suffix(i)] = V['bn_gamma'][sl]
+            out['encoder/batch_normalization%s/beta' % _suffix(i)] = V['bn_beta'][sl]
+            if bn_stats:
+                out['encoder/batch_normalization%s/moving_mean' % _suffix(i)] = self.bn_mean[sl]
+                out['encoder/batch_normalization%s/moving_variance' % _suffix(i)] = self.bn_var[sl]
+        out['embedding/embedding'] = V['embedding']
+        out['decoder/preprocess/kernel'] = V['pre_w'].reshape(self.pre_k, 1, R)
+        out['decoder/preprocess/bias'] = V['pre_b']
+        out['decoder/skip/kernel'] = V['skip0_w'].reshape(1, R, S)
+        out['decoder/skip/bias'] = V['skip0_b']
+        ncl = self.w['num_cycle_layers']
+        for l in range(L):
+            s = layer_scope(l, ncl)
+            out[s + '/gated/kernel'] = V['gated_w'][l]
+            out[s + '/gated/bias'] = V['gated_b'][l]
+            out[s + '/gated/local_condition/kernel'] = V['cond_w'][:, l * 2 * R:(l + 1) * 2 * R].unsqueeze(0)
+            out[s + '/skip/kernel'] = V['out_w'][l][:, :S].unsqueeze(0)
+            out[s + '/skip/bias'] = V['out_b'][l][:S]
+            out[s + '/residual/kernel'] = V['out_w'][l][:, S:].unsqueeze(0)
+            out[s + '/residual/bias'] = V['out_b'][l][S:]
+        out['decoder/postprocess1/kernel'] = V['post1_w'].reshape(1, S, S)
+        out['decoder/postprocess1/bias'] = V['post1_b']
+        out['decoder/postprocess1/local_condition/kernel'] = V['cond_w'][:, L * 2 * R:].unsqueeze(0)
+        out['decoder/postprocess2/kernel'] = V['post2_w'].reshape(1, S, self.Q)
+        out['decoder/postprocess2/bias'] = V['post2_b']
+        return out
+
+    def named_parameters(self, ema=False):
+        """Copies of all variables under the reference's names (ema=True: the EMA shadows
+        that generate.py:88-90 restores)."""
+        return OrderedDict((k, v.detach().clone()) for k, v in self._named(self.E if ema else self.P).items())
+
+    def named_gradients(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self._named(self.G, bn_stats=False).items())
+
+    def load_named(self, params, also_ema=True):
+        """Load variables given under the reference's names (any device)."""
+        dst = self._named(self.P)
+        for name, view in dst.items():
+            if name not in params:
+                raise KeyError('missing variable ' + name)
+            view.copy_(torch.as_tensor(params[name]).to(self.dev).reshape(view.shape))
+        if also_ema:
+            self.ema.copy_(self.flat)
+
+    def use_ema_weights(self):
+        """generate.py:88-90: restore the EMA shadow variables into the live variables."""
+        self.flat.copy_(self.ema)
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B, T):
+        key = (B, T)
+        if key in self._ws:
+            return self._ws[key]
+        if T % 64 != 0:
+            raise ValueError('length must be a multiple of 64 for Encoder_64 (got %d)' % T)
+        dev, F, D, R, S, Q, L = self.dev, self.F, self.D, self.R, self.S, self.Q, self.L
+        Tz = T // 64
+        e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+        ws = {'B': B, 'T': T, 'Tz': Tz, 'ratio': T // Tz}
+        ws['Tl'] = [T // (2 ** (i + 1)) for i in range(6)]
+        ws['inputs'] = e(B, T)
+        ws['labels'] = torch.empty(B, T, dtype=torch.int32, device=dev)
+        ws['X'] = [e(B, F, t) for t in ws['Tl']]      # BN outputs of encoder layers 0..5
+        ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
+        ws['y6'] = e(B, D, Tz)
+        ws['z_e'] = e(B, D, Tz)
+        ws['idx'] = torch.empty(B, Tz, dtype=torch.int64, device=dev)
+        ws['e_k'] = e(B, D, Tz)
+        ws['mind'] = e(B, Tz)
+        ws['cond'] = e(B, self.Cc, Tz)
+        ws['condenc'] = e(B, self.Mall, Tz)
+        ws['net'] = [e(B, R, T) for _ in range(L + 1)]
+        ws['skip'] = e(B, S, T)
+        ws['gated'] = [e(B, R, T) for _ in range(L)]
+        ws['th'] = [e(B, R, T) for _ in range(L)]
+        ws['sg'] = [e(B, R, T) for _ in range(L)]
+        ws['h1'] = e(B, S, T)
+        ws['logits'] = e(B, Q, T)
+        # backward
+        ws['dnet'] = e(B, R, T)
+        ws['dpre'] = e(B, 2 * R, T)
+        ws['dcondenc'] = e(B, self.Mall, Tz)
+        ws['dcond'] = e(B, self.Cc, Tz)
+        ws['dz'] = e(B, D, Tz)
+        ws['dX'] = [e(B, F, t) for t in ws['Tl']]
+        ws['bskip'] = e(S)
+        ws['scale'] = e(6 * F + D)
+        ws['shift'] = e(6 * F + D)
+        ws['dscale'] = e(6 * F + D)
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward pieces
+    def _bn_affine(self, ws):
+        """Inference-mode BatchNorm as a per-channel affine (encoder.py:20,25; Appendix A-3)."""
+        inv = torch.rsqrt(self.bn_var + BN_EPS)
+        torch.mul(self.P['bn_gamma'], inv, out=ws['scale'])
+        torch.addcmul(self.P['bn_beta'], self.bn_mean, ws['scale'], value=-1.0, out=ws['shift'])
+        return inv
+
+    def _encode(self, x, spk, ws, save=True):
+        """encoder.py:13-26 + model.py:57-74 + decoder_ops.py:39-43 -> ws['cond'] [B][Cc][Tz]."""
+        P, F, D, B, T = self.P, self.F, self.D, ws['B'], ws['T']
+        self._bn_affine(ws)
+        sc, sh = ws['scale'], ws['shift']
+        pl, _ = same_pads(T, 5, 2)
+        K.conv_cin1_fwd(x, P['enc_w0'], P['enc_b'][0], ws['X'][0], k=5, stride=2, offset=-pl, relu=True,
+                        scale=sc[:F], shift=sh[:F], save_r=ws['r'][0] if save else None)
+        Tin = ws['Tl'][0]
+        for i in range(1, 6):
+            Tout = ws['Tl'][i]
+            pl, _ = same_pads(Tin, 5, 2)
+            K.conv_gemm(x0=ws['X'][i - 1], w=P['enc_w'][i - 1], bias=P['enc_b'][i], out0=ws['X'][i],
+                        save0=ws['r'][i] if save else None, scale=sc[i * F:(i + 1) * F], shift=sh[i * F:(i + 1) * F],
+                        B=B, T_in=Tin, T_out=Tout, M=F, C0=F, in_stride=2, taps=[j - pl for j in range(5)],
+                        out_relu=True)
+            Tin = Tout
+        Tz = ws['Tz']
+        K.conv_gemm(x0=ws['X'][5], w=P['enc_w6'], bias=P['enc_b6'], out0=ws['z_e'], save0=ws['y6'] if save else None,
+                    scale=sc[6 * F:], shift=sh[6 * F:], B=B, T_in=Tz, T_out=Tz, M=D, C0=F, taps=[0])
+        K.vq_nearest_fwd(ws['z_e'], P['embedding'], idx=ws['idx'], e_k=ws['e_k'], zq=ws['cond'],
+                         zq_bstride=self.Cc * Tz, mind=ws['mind'])
+        K.speaker_tile_fwd(P['speaker_embedding'], spk, ws['cond'], cond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs, Tz=Tz)
+
+    def _decode_train(self, x, ws, save=True):
+        """wavenet.py:24-100 -> ws['logits'] [B][Q][T], ws['labels']."""
+        P, R, S, Q, L, B, T, Tz = self.P, self.R, self.S, self.Q, self.L, ws['B'], ws['T'], ws['Tz']
+        K.wavenet_inputs(x, ws['inputs'], ws['labels'])                                   # wavenet.py:33-37
+        K.conv_gemm(x0=ws['cond'], w=P['cond_w'], out0=ws['condenc'], B=B, T_in=Tz, T_out=Tz, M=self.Mall,
+                    C0=self.Cc, taps=[0])                                                 # all add_condition 1x1s
+        net = ws['net']
+        K.conv_cin1_fwd(ws['inputs'], P['pre_w'], P['pre_b'], net[0], k=self.pre_k, stride=1,
+                        offset=-(self.pre_k - 1))                                         # wavenet.py:42-44
+        K.conv_gemm(x0=net[0], w=P['skip0_w'], bias=P['skip0_b'], out0=ws['skip'], B=B, T_in=T, T_out=T, M=S,
+                    C0=R, taps=[0])                                                       # wavenet.py:53-54
+        cbs = self.Mall * Tz
+        ce_flat = ws['condenc'].view(-1)   # layer l's rows start at l*2R*Tz inside every batch block
+        for l, d in enumerate(self.dil):
+            K.conv_gemm(x0=net[l], w=P['gated_w'][l], bias=P['gated_b'][l], out0=ws['gated'][l],
+                        save0=ws['th'][l] if save else None, save1=ws['sg'][l] if save else None,
+                        cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T,
+                        M=2 * R, C0=R, taps=[-(self.ks - 1 - j) * d for j in range(self.ks)],
+                        epilogue=K.EPI_GATE)                                              # wavenet_ops.py:104-114
+            K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
+                        aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
+                        epilogue=K.EPI_ACCUM_SPLIT)                                       # :132-136, wavenet.py:72-73
+        K.conv_gemm(x0=ws['skip'], in_relu=True, w=P['post1_w'], bias=P['post1_b'], out0=ws['h1'],
+                    cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T, M=S,
+                    C0=S, taps=[0])                                                       # wavenet.py:80-88
+        K.conv_gemm(x0=ws['h1'], in_relu=True, w=P['post2_w'], bias=P['post2_b'], out0=ws['logits'], B=B, T_in=T,
+                    T_out=T, M=Q, C0=S, taps=[0])                                         # wavenet.py:94-96
+
+    def forward(self, x, spk, compute_grad_seed=True):
+        """model.py:145-151 up to the losses.  x [B][T] raw audio in [-1,1], spk int64 [B].
+        Leaves logits (or d loss/d logits when compute_grad_seed) in the workspace and the
+        loss sums in self.loss_buf (no host sync)."""
+        B, T = x.shape
+        ws = self._workspace(B, T)
+        self._encode(x, spk, ws)
+        self._decode_train(x, ws)
+        self.loss_buf.zero_()
+        N = B * T
+        K.softmax_xent(ws['logits'], ws['labels'], loss_sum=self.loss_buf[0:1],
+                       dlogits=ws['logits'] if compute_grad_seed else None, grad_scale=1.0 / N)  # model.py:91-94
+        K.rowsum(ws['mind'].view(1, 1, -1), total=self.loss_buf[1:2])
+        return ws
+
+    def losses(self, ws):
+        """(loss, reconstruction, vq, commitment) as python floats (synchronises)."""
+        v = self.loss_buf.tolist()
+        recon = v[0] / (ws['B'] * ws['T'])
+        vq = v[1] / (ws['B'] * ws['Tz'] * self.D)          # model.py:100
+        commit = self.beta * vq                             # model.py:103 (same forward value)
+        return recon + vq + commit, recon, vq, commit
+
+    # ------------------------------------------------------------------ backward
+    def _transpose_weights(self):
+        P, Tt, L, ks, R, S, F = self.P, self.T, self.L, self.ks, self.R, self.S, self.F
+        K.transpose(P['gated_w'], Tt['gated_w'], L * ks, R, 2 * R)
+        K.transpose(P['out_w'], Tt['out_w'], L, R, S + R)
+        K.transpose(P['post1_w'], Tt['post1_w'], 1, S, S)
+        K.transpose(P['post2_w'], Tt['post2_w'], 1, S, self.Q)
+        K.transpose(P['skip0_w'], Tt['skip0_w'], 1, R, S)
+        K.transpose(P['cond_w'], Tt['cond_w'], 1, self.Cc, self.Mall)
+        K.transpose(P['enc_w'], Tt['enc_w'], 25, F, F)
+        K.transpose(P['enc_w6'], Tt['enc_w6'], 1, F, self.D)
+
+    def backward(self, x, spk, ws):
+        """Gradients of loss = CE + vq + commitment (model.py:90-106) w.r.t. every trainable
+        variable, accumulated into self.grad (zeroed here)."""
+        P, G, Tt = self.P, self.G, self.T
+        R, S, Q, L, F, D, ks = self.R, self.S, self.Q, self.L, self.F, self.D, self.ks
+        B, T, Tz, ratio = ws['B'], ws['T'], ws['Tz'], ws['ratio']
+        self.grad.zero_()
+        self._transpose_weights()
+        dlog, h1, skip = ws['logits'], ws['h1'], ws['skip']
+        cbs = self.Mall * Tz
+        dce = ws['dcondenc']
+        # ---- postprocess2 (wavenet.py:93-96)
+        K.wgrad_gemm(p=h1, p_relu=True, q0=dlog, dw=G['post2_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=Q, taps=[0])
+        K.rowsum(dlog, total=G['post2_b'])
+        K.conv_gemm(x0=dlog, w=Tt['post2_w'], out0=h1, aux0=h1, B=B, T_in=T, T_out=T, M=S, C0=Q, taps=[0],
+                    epilogue=K.EPI_MASK)                       # h1 := d h1 (pre-relu)
+        # ---- postprocess1 (wavenet.py:79-88)
+        K.wgrad_gemm(p=skip, p_relu=True, q0=h1, dw=G['post1_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=S, taps=[0])
+        seg_p1 = torch.empty(B, S, Tz, device=self.dev)
+        K.rowsum(h1, seg_out=seg_p1, total=G['post1_b'], seg=ratio)
+        dce[:, L * 2 * R:].copy_(seg_p1)
+        K.conv_gemm(x0=h1, w=Tt['post1_w'], out0=skip, aux0=skip, B=B, T_in=T, T_out=T, M=S, C0=S, taps=[0],
+                    epilogue=K.EPI_MASK)                       # skip := d skip (same for every layer)
+        dskip = skip
+        ws['bskip'].zero_()
+        K.rowsum(dskip, total=ws['bskip'])
+        G['out_b'][:, :S] += ws['bskip']
+        G['skip0_b'] += ws['bskip']
+        # ---- residual stack, top layer first (wavenet.py:63-74)
+        dnet, dpre, net = ws['dnet'], ws['dpre'], ws['net']
+        seg_l = torch.empty(B, 2 * R, Tz, device=self.dev)
+        for l in range(L - 1, -1, -1):
+            d = self.dil[l]
+            top = (l == L - 1)       # net[L] is unused by the graph: its gradient is zero
+            K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
+                        aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
+                        epilogue=K.EPI_GATE_BWD)
+            K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
+                         Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
+            if not top:
+                K.rowsum(dnet, total=G['out_b'][l][S:])
+            taps_b = [(ks - 1 - j) * d for j in range(ks)]
+            if top:
+                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b)
+            else:
+                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T,
+                            M=R, M0=0, C0=2 * R, taps=taps_b, epilogue=K.EPI_ACCUM_SPLIT)
+            K.wgrad_gemm(p=net[l], q0=dpre, dw=G['gated_w'][l], B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
+                         taps=[-(ks - 1 - j) * d for j in range(ks)])
+            K.rowsum(dpre, seg_out=seg_l, total=G['gated_b'][l], seg=ratio)
+            dce[:, l * 2 * R:(l + 1) * 2 * R].copy_(seg_l)
+        # ---- skip start + preprocess (wavenet.py:42-55)
+        K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
+                    C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
+        K.wgrad_gemm(p=net[0], q0=dskip, dw=G['skip0_w'], B=B, T_q=T, T_p=T, Cp=R, Q0=S, taps=[0])
+        K.conv_cin1_wgrad(ws['inputs'], dnet, G['pre_w'], k=self.pre_k, stride=1, offset=-(self.pre_k - 1))
+        K.rowsum(dnet, total=G['pre_b'])
+        # ---- local condition (wavenet_ops.py:93-101) -> d cond
+        K.wgrad_gemm(p=ws['cond'], q0=dce, dw=G['cond_w'], B=B, T_q=Tz, T_p=Tz, Cp=self.Cc, Q0=self.Mall, taps=[0])
+        K.conv_gemm(x0=dce, w=Tt['cond_w'], out0=ws['dcond'], B=B, T_in=Tz, T_out=Tz, M=self.Cc, C0=self.Mall, taps=[0])
+        # ---- speaker embedding + VQ (model.py:22-27, 57-74, 99-106)
+        K.speaker_tile_bwd(ws['dcond'], spk, G['speaker_embedding'], dcond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs, Tz=Tz)
+        nd = float(B * Tz * D)
+        K.vq_nearest_bwd(ws['z_e'], ws['e_k'], ws['idx'], dzq=ws['dcond'], dzq_bstride=self.Cc * Tz, dz_e=ws['dz'],
+                         demb=G['embedding'], cscale=2.0 * self.beta / nd, escale=2.0 / nd, K=self.Kc)
+        # ---- encoder (encoder.py:13-26), BN in inference mode
+        sc, dsc = ws['scale'], ws['dscale']
+        dsc.zero_()
+        dz = ws['dz']
+        K.rowsum(dz, y=ws['y6'], total=dsc[6 * F:])
+        K.rowsum(dz, total=G['bn_beta'][6 * F:])
+        K.bn_relu_bwd(dz, None, sc[6 * F:], dz)                      # dz := d(conv6 output)
+        K.wgrad_gemm(p=ws['X'][5], q0=dz, dw=G['enc_w6'], B=B, T_q=Tz, T_p=Tz, Cp=F, Q0=D, taps=[0])
+        K.rowsum(dz, total=G['enc_b6'])
+        K.conv_gemm(x0=dz, w=Tt['enc_w6'], out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
+        for i in range(5, -1, -1):
+            dX, r = ws['dX'][i], ws['r'][i]
+            Ti = ws['Tl'][i]
+            K.rowsum(dX, y=r, total=dsc[i * F:(i + 1) * F])
+            K.rowsum(dX, total=G['bn_beta'][i * F:(i + 1) * F])
+            K.bn_relu_bwd(dX, r, sc[i * F:(i + 1) * F], dX)          # dX := d(conv_i output)
+            K.rowsum(dX, total=G['enc_b'][i])
+            Tin = ws['Tl'][i - 1] if i > 0 else T
+            pl, _ = same_pads(Tin, 5, 2)
+            if i == 0:
+                K.conv_cin1_wgrad(x, dX, G['enc_w0'], k=5, stride=2, offset=-pl)
+                break
+            K.wgrad_gemm(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], B=B, T_q=Ti, T_p=Tin, Cp=F, Q0=F, p_stride=2,
+                         taps=[j - pl for j in range(5)])
+            # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
+            for p in (0, 1):
+                j0 = (p + pl) % 2
+                js = list(range(j0, 5, 2))
+                K.conv_gemm(x0=dX, w=Tt['enc_w'][i - 1][j0:], w_tap_stride=2 * F * F, out0=ws['dX'][i - 1], B=B,
+                            T_in=Ti, T_out=(Tin - p + 1) // 2, M=F, C0=F, taps=[(p + pl - j) // 2 for j in js],
+                            out_tstride=2, out_toffset=p, T_store=Tin)
+        dsc.addcmul_(self.bn_mean, G['bn_beta'], value=-1.0)         # shift = beta - mean*scale
+        torch.mul(dsc, torch.rsqrt(self.bn_var + BN_EPS), out=dsc)
+        G['bn_gamma'] += dsc
+
+    # ------------------------------------------------------------------ optimiser
+    def lr_at(self, step):
+        """Piecewise-constant schedule of model.py:111-114."""
+        lr = self.schedule[0][1]
+        for key, value in self.schedule:
+            if not (step < key):
+                lr = value
+        return lr
+
+    def apply_gradients(self, grad_scale=1.0):
+        """TF-1.x Adam + EMA(0.999) (model.py:116-128)."""
+        t = self.global_step + 1
+        lr = self.lr_at(self.global_step)
+        lr_t = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+        K.adam_ema_step(self.flat, self.grad, self.adam_m, self.adam_v, self.ema, lr_t=lr_t, grad_scale=grad_scale)
+        self.global_step = t
+        return lr
+
+    def train_step(self, x, spk, allreduce=None):
+        """One sess.run(train_op) (train.py:104-114).  `allreduce(flat_grad)` sums gradients
+        over data-parallel ranks (RCCL); it returns the world size."""
+        ws = self.forward(x, spk)
+        self.backward(x, spk, ws)
+        world = allreduce(self.grad) if allreduce is not None else 1
+        self.apply_gradients(1.0 / world)
+        return ws
+
+    # ------------------------------------------------------------------ generation
+    def encode(self, x, spk):
+        """model.encoding of generate.py:92: [B][Cc][Tz] (channel-major)."""
+        B, T = x.shape
+        ws = self._workspace(B, T)
+        self._encode(x, spk, ws, save=False)
+        return ws['cond'].clone()
+
+    def state_dict(self):
+        return {'flat': self.flat, 'ema': self.ema, 'adam_m': self.adam_m, 'adam_v': self.adam_v,
+                'bn_mean': self.bn_mean, 'bn_var': self.bn_var,
+                'global_step': torch.tensor(self.global_step, dtype=torch.int64)}
+
+    def load_state_dict(self, sd):
+        for k in ('flat', 'ema', 'adam_m', 'adam_v', 'bn_mean', 'bn_var'):
+            getattr(self, k).copy_(sd[k].to(self.dev))
+        self.global_step = int(sd['global_step'])
