@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Benchmark of the VQ-VAE-WaveNet hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one full training step (forward + backward + gradient all-reduce over RCCL for
+N > 1 + TF-Adam + EMA) on synthetic 16 kHz segments, len=6656, batch=8 PER GPU (weak scaling),
+default config (encoder '64', K=512, 30-layer WaveNet), fp32 -- BASELINE.json configs[1].
+Rank 0 prints ONE JSON line: training audio-samples/s for the whole job, the roofline of the
+dominant kernel (the gated dilated conv, MFMA-bound: SURVEY.md 8(d)) measured live with HIP
+events on the launch stream, the CPU baseline (the oracle restatement timed on this box's host
+cores; rank 0 at N=1 only) and the fast-generation rate.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(B, T, num_speakers, seed, device):
+    """int16 PCM of 4 sinusoids + envelope + noise -> x=(pcm+0.5)/32767.5."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    n = torch.arange(T, dtype=torch.float64)
+    f = 80 + (3400 - 80) * torch.rand(B, 4, generator=g, dtype=torch.float64)
+    ph = 2 * math.pi * torch.rand(B, 4, generator=g, dtype=torch.float64)
+    env = 0.6 + 0.4 * torch.sin(2 * math.pi * n / T * (1 + 3 * torch.rand(B, 1, generator=g, dtype=torch.float64)))
+    s = torch.sin(2 * math.pi * f[:, :, None] * n / 16000.0 + ph[:, :, None]).sum(1)
+    noise = torch.randn(B, T, generator=g, dtype=torch.float64)
+    wav = torch.clamp(0.25 * s * env + 0.02 * noise, -1, 1)
+    pcm = torch.round(wav * 32767).to(torch.int16)
+    x = ((pcm.to(torch.float32) + 0.5) / 32767.5)
+    spk = torch.randint(0, num_speakers, (B,), generator=g)
+    return x.to(device), spk.to(device)
+
+
+def default_configs():
+    m = {"encoder": "64", "use_vq": True, "speaker_embedding": 64, "k": 512, "latent_dim": 64, "beta": 0.25,
+         "learning_rate_schedule": {"0": 8e-5, "80000": 6e-5, "160000": 4e-5, "240000": 2e-5, "320000": 1e-5,
+                                    "400000": 8e-6}}
+    w = {"quantization_channels": 256, "num_cycles": 3, "num_cycle_layers": 10,
+         "dilation_rates": [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3, "kernel_size": 3,
+         "dilation_filters": 256, "skip_filters": 512, "residual_filters": 256,
+         "preprocess": {"kernel_size": 32, "filters": 256}}
+    for name, cfg in (('model_parameters.json', m), ('wavenet_parameters.json', w)):
+        p = os.path.join(ROOT, name)
+        if os.path.exists(p):
+            with open(p) as fh:
+                cfg.update(json.load(fh))
+    return m, w
+
+
+class GateConvTimer:
+    """HIP events around every launch of the dominant kernel, on the launch stream."""
+
+    def __init__(self, kernels_mod):
+        self.K = kernels_mod
+        self.orig = kernels_mod.conv_gemm
+        self.events = []
+        self.on = False
+
+    def __enter__(self):
+        K = self.K
+
+        def wrapped(**kw):
+            if self.on and kw.get('epilogue') == K.EPI_GATE:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.orig(**kw)
+                e1.record()
+                self.events.append((e0, e1))
+            else:
+                self.orig(**kw)
+        K.conv_gemm = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.K.conv_gemm = self.orig
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
+
+
+def log(*a):
+    print('[bench]', *a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use (the GPU box gives a 16-core share of a big host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get('VQW_CPU_THREADS', '16'))))
+
+
+def cpu_baseline(B, T, steps):
+    """The oracle (a torch-CPU fp32 restatement of the reference graph: 'port') timed on the
+    host cores of this box: full training steps at batch 1 (BASELINE.json configs[0])."""
+    from oracle import ref_model as M
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log('cpu baseline: %d threads' % cores)
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    P = M.init_params(m, w, 109, seed=0)
+    x, spk, _ = M.synthetic_batch(B, T, 109, 1234)
+    st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
+    M.train_step(x, spk, P, m, w, st, 0)            # warm-up
+    log('cpu baseline: warm-up step done')
+    t0 = time.time()
+    for i in range(steps):
+        M.train_step(x, spk, P, m, w, st, i + 1)
+    dt = (time.time() - t0) / steps
+    return {"value": B * T / dt, "unit": "audio-samples/s", "cores": cores, "kind": "port",
+            "sample": "%d full training steps (fwd+bwd+Adam+EMA) of the torch-CPU oracle at batch=%d len=%d, "
+                      "after 1 warm-up step" % (steps, B, T), "ms_per_step": dt * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--length', type=int, default=6656)
+    ap.add_argument('--gen-steps', type=int, default=1024, help='AR samples to generate for the generation rate')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gen', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module('vq-vae-wavenet_amd')
+    K = pkg.kernels
+    m, w = default_configs()
+    S = 109
+    model = pkg.model.VQVAE(m, w, S, device=dev, seed=0)           # identical weights on every rank
+    B, T = a.batch, a.length
+    x, spk = synthetic_batch(B, T, S, 1234 + rank, dev)             # per-rank data
+
+    def allreduce(flat):
+        dist.all_reduce(flat)   # RCCL sum over xGMI; one 140.6 MB fp32 payload
+        return world
+    ar = allreduce if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log('model built, %d parameters; warm-up' % model.n_flat)
+    with GateConvTimer(K) as gt:
+        for _ in range(a.warmup):
+            model.train_step(x, spk, ar)
+        barrier()
+        log('timing %d steps' % a.steps)
+        gt.on = True
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            ws = model.train_step(x, spk, ar)
+        barrier()
+        dt = time.perf_counter() - t0
+        gt.on = False
+        gate_ms = gt.mean_ms()
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss = model.losses(ws)[0]
+    log('train: %.2f ms/step, loss %.5f' % (dt / a.steps * 1e3, loss))
+
+    gen = None
+    if not a.no_gen:
+        gen_mod = pkg.generator
+        enc = model.encode(x[:1].contiguous(), spk[:1].contiguous())          # one utterance per GPU
+        g = gen_mod.FastGenerator(model, batch=1)
+        g.generate(enc, 64)                                                    # warm-up + graph capture
+        torch.cuda.synchronize()
+        g.reset()
+        t1 = time.perf_counter()
+        g.generate(enc, a.gen_steps)
+        torch.cuda.synchronize()
+        gdt = time.perf_counter() - t1
+        gsum = torch.tensor([a.gen_steps / gdt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(gsum)
+        gen = {"metric": "AR-gen samples/sec", "value": float(gsum.item()), "unit": "samples/s",
+               "utterances": world, "batch_per_gpu": 1, "steps": a.gen_steps, "mode": "greedy",
+               "us_per_sample": gdt / a.gen_steps * 1e6}
+        g.close()
+        log('generation: %.1f us/sample' % (gdt / a.gen_steps * 1e6))
+
+    if rank == 0:
+        R, ks = model.R, model.ks
+        flops_gate = 2.0 * B * T * (ks * R) * (2 * R)       # K1: causal dilated conv 256 -> 512, k=3
+        ach = flops_gate / (gate_ms * 1e-3) / 1e12
+        rec = {
+            "metric": "training audio-samples/sec", "value": B * T * a.steps * world / dt,
+            "unit": "audio-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VCTK '64' encoder, len=%d batch=%d per GPU, fp32, full train step "
+                                   "(fwd+bwd+allreduce+Adam+EMA)" % (T, B),
+                       "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
+            "loss": loss,
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<2,4,GATE> (dilated k=3 conv 256->512 + cond + gate)",
+                         "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "ms_per_launch": gate_ms, "flop_per_launch": flops_gate,
+                         "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
+        }
+        if gen:
+            rec["ar_gen"] = gen
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(1, T, 2)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

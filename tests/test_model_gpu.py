@@ -39,7 +39,7 @@ def l2err(a, b):
     return float((a - b).norm()) / max(float(b.norm()), 1e-30)
 
 
-def run_parity(pkg, m, w, S, B, T, seed, steps=1, grad_tol=2e-3, err=relerr):
+def run_parity(pkg, m, w, S, B, T, seed, steps=1, grad_tol=2e-3, err=relerr, check_params=True):
     P = M.init_params(m, w, S, seed=seed, randomize_all=True)
     x, spk, _ = M.synthetic_batch(B, T, S, 1234)
     model = build(pkg, m, w, S, P)
@@ -65,12 +65,14 @@ def run_parity(pkg, m, w, S, B, T, seed, steps=1, grad_tol=2e-3, err=relerr):
             if e > worst[1]:
                 worst = (name, e)
             assert e < grad_tol, 'grad %s rel err %.3e at step %d' % (name, e, step)
+        if not check_params:
+            continue
         newp = model.named_parameters()
         for name, pref in P.items():
-            assert relerr(newp[name], pref) < 1e-4, 'param %s after step %d' % (name, step)
+            assert err(newp[name], pref) < 1e-4, 'param %s after step %d' % (name, step)
         ema = model.named_parameters(ema=True)
         for name in grads:
-            assert relerr(ema[name], st['ema'][name]) < 1e-4, 'ema %s' % name
+            assert err(ema[name], st['ema'][name]) < 1e-4, 'ema %s' % name
     return worst
 
 
@@ -108,7 +110,7 @@ def test_default_width_short_segment(pkg):
     within one fp32 ulp of zero can flip its mask between CPU and GPU (observed: skip value
     9e-7), which moves single gradient elements by their full value but not the norm."""
     m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
-    worst = run_parity(pkg, m, w, 109, 1, 1024, seed=3, steps=1, grad_tol=5e-3, err=l2err)
+    worst = run_parity(pkg, m, w, 109, 1, 1024, seed=3, steps=1, grad_tol=5e-3, err=l2err, check_params=False)   # Adam step: kernel test + tiny-model tests
     print('worst grad', worst)
 
 
@@ -128,3 +130,60 @@ def test_data_parallel_shards_sum_to_full_batch(pkg):
         parts.append(mdl.grad.clone())
     avg = (parts[0] + parts[1]) / 2
     assert relerr(avg, full.grad) < 2e-3
+
+
+def test_fast_generation_matches_oracle(pkg):
+    """vqw_ar_decode (ring buffers + on-device decode) vs the oracle's FIFO-queue generator
+    (wavenet_ops.py:147-267, generate.py:103-113): greedy indices and sampling with supplied
+    uniforms; a mismatch is only accepted where the oracle's own decision is a near-tie."""
+    m, w = tiny_cfg()
+    P = M.init_params(m, w, 10, seed=11, randomize_all=True)
+    model = build(pkg, m, w, 10, P)
+    x, spk, _ = M.synthetic_batch(2, 512, 10, 1234)
+    xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
+    with torch.no_grad():
+        enc_ref = M.forward(x, spk, P, m, w)['local_condition']          # [B,Tz,Cc]
+    enc = model.encode(xd, sd)
+    assert relerr(enc.permute(0, 2, 1), enc_ref) < 1e-5
+    n = 160                                                                # crosses two condition frames
+    gen = pkg.generator.FastGenerator(model, batch=2)
+    audio, idx, probs = gen.generate(enc, n, return_probs=True)
+    got, ga = idx.cpu().numpy(), audio.cpu().numpy()
+    np.testing.assert_allclose(ga, M.R.mu_law_decode_np(got.astype(np.float32)), rtol=1e-5, atol=1e-6)
+    # teacher-force the ORACLE with the GPU's own samples: every GPU decision must be the
+    # oracle's argmax (or tie with it within fp32 noise), and the last probabilities must agree
+    g = M.FastGenerator(P, w, 2)
+    a = np.zeros([2, 1], np.float32)
+    with torch.no_grad():
+        for i in range(n):
+            pr = g.step(torch.from_numpy(a), enc_ref[:, i // 64]).numpy()
+            for b in range(2):
+                assert pr[b].max() - pr[b, got[b, i]] <= 2e-6, \
+                    'step %d row %d: GPU chose %d (p=%.8f), oracle argmax %d (p=%.8f)' % (
+                        i, b, got[b, i], pr[b, got[b, i]], pr[b].argmax(), pr[b].max())
+            a = ga[:, i:i + 1]
+    np.testing.assert_allclose(probs.cpu().numpy(), pr, rtol=2e-4, atol=1e-7)
+    # continuing a run == one long run (ring-buffer state carries over)
+    gen.reset()
+    a1, i1 = gen.generate(enc, 100)
+    a2, i2 = gen.generate(enc, 60)
+    assert torch.equal(torch.cat([i1, i2], 1), idx)
+    # sampling with supplied uniforms (utils.py:13-27)
+    u = torch.rand(2, n, generator=torch.Generator().manual_seed(0))
+    gen.reset()
+    sa, si = gen.generate(enc, n, mode='sample', uniforms=u.cuda())
+    si, sa = si.cpu().numpy(), sa.cpu().numpy()
+    g = M.FastGenerator(P, w, 2)
+    a = np.zeros([2, 1], np.float32)
+    with torch.no_grad():
+        for i in range(n):
+            pr = g.step(torch.from_numpy(a), enc_ref[:, i // 64]).numpy()
+            cdf = np.cumsum(pr, axis=1)
+            for b in range(2):
+                want = int(cdf[b].searchsorted(u[b, i].item()))
+                if want != si[b, i]:   # only acceptable when u sits on a cdf edge (fp32 noise)
+                    assert np.abs(cdf[b] - u[b, i].item()).min() < 2e-6, 'step %d row %d: %d vs %d' % (i, b, si[b, i], want)
+            a = sa[:, i:i + 1]
+    gen.close()
+    with pytest.raises(NotImplementedError):
+        pkg.generator.FastGenerator(model, batch=1).generate(enc[:1].contiguous(), 4, mode='beam')

@@ -1,0 +1,79 @@
+"""Fast autoregressive generation: host-side mirror of Wavenet.build_generator
+(wavenet.py:103-172) + the sampling loop of generate.py:103-113, running entirely on the GPU
+through vqw_ar_decode_* (ring buffers instead of FIFO queues, on-device sampling)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class FastGenerator:
+    def __init__(self, model, batch):
+        """Uses the model's LIVE variables (call model.use_ema_weights() first to mirror
+        generate.py:88-90, which restores the EMA shadows)."""
+        self.model, self.B = model, batch
+        P = model.P
+        nl, R, S = model.L, model.R, model.S
+        w = L.ArWeights()
+        w.n_layers, w.kernel_size, w.R, w.S, w.Q, w.Cc, w.pre_k = nl, model.ks, R, S, model.Q, model.Cc, model.pre_k
+        self._dil = (C.c_int32 * nl)(*model.dil)
+        w.dilations = self._dil
+        f4 = 4  # bytes per float
+
+        def arr(ptrs):
+            a = (C.c_void_p * nl)(*ptrs)
+            return a
+        self._gw = arr([P['gated_w'][l].data_ptr() for l in range(nl)])
+        self._gb = arr([P['gated_b'][l].data_ptr() for l in range(nl)])
+        self._cw = arr([P['cond_w'].data_ptr() + l * 2 * R * f4 for l in range(nl)])
+        self._ow = arr([P['out_w'][l].data_ptr() for l in range(nl)])
+        self._ob = arr([P['out_b'][l].data_ptr() for l in range(nl)])
+        w.gated_w, w.gated_b, w.cond_w, w.out_w, w.out_b = self._gw, self._gb, self._cw, self._ow, self._ob
+        w.cond_ld, w.out_ld = model.Mall, S + R
+        w.pre_w, w.pre_b = P['pre_w'].data_ptr(), P['pre_b'].data_ptr()
+        w.skip0_w, w.skip0_b = P['skip0_w'].data_ptr(), P['skip0_b'].data_ptr()
+        w.post1_w, w.post1_b = P['post1_w'].data_ptr(), P['post1_b'].data_ptr()
+        w.post1_cond_w, w.post1_cond_ld = P['cond_w'].data_ptr() + nl * 2 * R * f4, model.Mall
+        w.post2_w, w.post2_b = P['post2_w'].data_ptr(), P['post2_b'].data_ptr()
+        self._w = w
+        self._h = C.c_void_p()
+        L.check(L.lib().vqw_ar_decode_create(C.byref(self._h), C.byref(w), batch))
+
+    def reset(self):
+        """sess.run(wavenet.init_ops) (generate.py:105)."""
+        L.check(L.lib().vqw_ar_decode_reset(self._h, L.stream()))
+
+    def generate(self, encoding, n_steps, mode='greedy', uniforms=None, ratio=None, return_probs=False):
+        """encoding [B][Cc][Tz] (model.encode); continues from the current queue state.
+        Returns (audio [B][n] float32, indices [B][n] int32[, probs of the last step [B][Q]])."""
+        if mode not in ('greedy', 'sample'):
+            raise NotImplementedError('decode mode %s not implemented' % mode)   # utils.py:46
+        B, Cc, Tz = encoding.shape
+        if B != self.B or Cc != self.model.Cc:
+            raise ValueError('encoding must be [%d][%d][Tz]' % (self.B, self.model.Cc))
+        L.require_cuda(encoding, uniforms)
+        ratio = ratio or 64
+        dev = encoding.device
+        audio = torch.empty(B, n_steps, device=dev)
+        idx = torch.empty(B, n_steps, dtype=torch.int32, device=dev)
+        probs = torch.empty(B, self.model.Q, device=dev) if return_probs else None
+        if mode == 'sample':
+            if uniforms is None:
+                uniforms = torch.rand(B, n_steps, device=dev)        # np.random.rand in utils.py:22
+            if uniforms.shape != (B, n_steps) or uniforms.dtype != torch.float32:
+                raise ValueError('uniforms must be float32 [B][n_steps]')
+        L.check(L.lib().vqw_ar_decode_run(self._h, L.ptr(encoding), Tz, ratio, n_steps, 0 if mode == 'greedy' else 1,
+                                          L.ptr(uniforms), L.ptr(audio), L.ptr(idx), L.ptr(probs), L.stream()))
+        return (audio, idx, probs) if return_probs else (audio, idx)
+
+    def close(self):
+        if self._h:
+            L.lib().vqw_ar_decode_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
