@@ -17,6 +17,8 @@
 // owns MT x NT tiles of 32x32; tile e of the M direction holds rows m = MT*r + e and tile f
 // of the N direction holds columns t = NT*c + f, so one ds_read_b64/b128 per lane fetches
 // the operands of all MT (NT) tiles and every accumulator row stores NT contiguous floats.
+#include <type_traits>
+
 #include "vqw_common.h"
 
 namespace {
@@ -37,49 +39,14 @@ __device__ __forceinline__ float tanh_f(float x) {
     return 1.0f - 2.0f / (e + 1.0f);
 }
 
-// 4 activations x[stride*t + ...] for 4 consecutive output times, zero outside [0,T_in).
-__device__ __forceinline__ f32x4 load_x4(const float* __restrict__ row, int ti, int T_in,
-                                         int stride, int relu) {
-    f32x4 v;
-    if (stride == 1) {
-        if (ti >= 0 && ti + 3 < T_in) {
-            const F4U u = *reinterpret_cast<const F4U*>(row + ti);
-            v = {u.x, u.y, u.z, u.w};
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int tt = ti + e;
-                v[e] = (tt >= 0 && tt < T_in) ? row[tt] : 0.0f;
-            }
-        }
-    } else {
-        if (ti >= 0 && ti + 7 < T_in) {
-            const F4U u0 = *reinterpret_cast<const F4U*>(row + ti);
-            const F4U u1 = *reinterpret_cast<const F4U*>(row + ti + 4);
-            v = {u0.x, u0.z, u1.x, u1.z};
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int tt = ti + stride * e;
-                v[e] = (tt >= 0 && tt < T_in) ? row[tt] : 0.0f;
-            }
-        }
-    }
-    if (relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-    }
-    return v;
-}
-
 template <int NT>
 __device__ __forceinline__ void store_row(float* __restrict__ rowp, int tb, int T_out,
                                           int tstride, int toff, int vec_ok,
                                           const float (&v)[NT]) {
-    if (vec_ok && tb + NT <= T_out) {
+    if (NT > 1 && vec_ok && tb + NT <= T_out) {
         if constexpr (NT == 4) {
             *reinterpret_cast<f32x4*>(rowp + tb) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
+        } else if constexpr (NT == 2) {
             *reinterpret_cast<f32x2*>(rowp + tb) = f32x2{v[0], v[1]};
         }
     } else {
@@ -92,11 +59,11 @@ __device__ __forceinline__ void store_row(float* __restrict__ rowp, int tb, int 
 template <int NT>
 __device__ __forceinline__ void load_row(const float* __restrict__ rowp, int tb, int T_out,
                                          int tstride, int toff, int vec_ok, float (&v)[NT]) {
-    if (vec_ok && tb + NT <= T_out) {
+    if (NT > 1 && vec_ok && tb + NT <= T_out) {
         if constexpr (NT == 4) {
             const f32x4 u = *reinterpret_cast<const f32x4*>(rowp + tb);
             v[0] = u[0]; v[1] = u[1]; v[2] = u[2]; v[3] = u[3];
-        } else {
+        } else if constexpr (NT == 2) {
             const f32x2 u = *reinterpret_cast<const f32x2*>(rowp + tb);
             v[0] = u[0]; v[1] = u[1];
         }
@@ -108,7 +75,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rowp, int tb,
 }
 
 template <int MT, int NT, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int A_F4 = (BK * BM / 4) / 256;  // float4 per thread, weight tile
     constexpr int B_F4 = (BK * BN / 4) / 256;  // float4 per thread, activation tile
@@ -159,48 +126,70 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
         return j;
     };
 
-    auto load_tiles = [&](int tap, int kc) {
-        // ---- weights
+    // Staging loads.  Everything that decides the code path is block-uniform, so the fast
+    // path is straight-line: all global loads of a K-step issue back to back and stay in
+    // flight under the MFMAs of the previous step.
+    auto load_tiles = [&](auto fast_tag, int tap, int kc) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        // ---- weights (columns beyond M are clamped, then zeroed: no divergent branch)
+        const float* wt = d.w + (size_t)tap * d.w_tap_stride + (size_t)kc * d.ldw;
         if constexpr (GATE) {
             const int kk = tid / (BM / 8), u2 = tid % (BM / 8);
             const int g = o0 + 4 * u2;
-            const size_t wrow = (size_t)tap * d.w_tap_stride + (size_t)(kc + kk) * d.ldw;
-            if (g < a.H) {
-                ra[0] = *reinterpret_cast<const f32x4*>(d.w + wrow + g);
-                ra[1] = *reinterpret_cast<const f32x4*>(d.w + wrow + a.H + g);
-            } else {
-                ra[0] = f32x4{0, 0, 0, 0};
-                ra[1] = f32x4{0, 0, 0, 0};
-            }
+            const int gc = min(g, a.H - 4);
+            const float* wr = wt + (size_t)kk * d.ldw;
+            ra[0] = *reinterpret_cast<const f32x4*>(wr + gc);
+            ra[1] = *reinterpret_cast<const f32x4*>(wr + a.H + gc);
+            if (g >= a.H) { ra[0] = f32x4{0, 0, 0, 0}; ra[1] = f32x4{0, 0, 0, 0}; }
         } else {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const int idx = tid + i * 256;
                 const int kk = idx / (BM / 4), u = idx % (BM / 4);
                 const int o = o0 + 4 * u;
-                const size_t wrow = (size_t)tap * d.w_tap_stride + (size_t)(kc + kk) * d.ldw;
-                ra[i] = (o < d.M) ? *reinterpret_cast<const f32x4*>(d.w + wrow + o)
-                                  : f32x4{0, 0, 0, 0};
+                const int oc = min(o, d.M - 4);
+                ra[i] = *reinterpret_cast<const f32x4*>(wt + (size_t)kk * d.ldw + oc);
+                if (o >= d.M) ra[i] = f32x4{0, 0, 0, 0};
             }
         }
         // ---- activations (the dilated / strided window of this tap)
         const int shift = d.tap_shift[tap];
-        const float* xb;
-        int cbase;
-        if (kc < d.C0) {
-            xb = d.x0 + (size_t)b * d.C0 * d.T_in;
-            cbase = kc;
-        } else {
-            xb = d.x1 + (size_t)b * d.C1 * d.T_in;
-            cbase = kc - d.C0;
-        }
+        const float* xb = (kc < d.C0) ? d.x0 + ((size_t)b * d.C0 + kc) * d.T_in
+                                      : d.x1 + ((size_t)b * d.C1 + (kc - d.C0)) * d.T_in;
+        const int lo = d.in_stride * t0 + shift;
+        if constexpr (FAST) {   // every active tap of this block is fully inside [0,T_in)
+            if (d.in_stride == 1) {
 #pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            const int idx = tid + i * 256;
-            const int kk = idx / (BN / 4), u = idx % (BN / 4);
-            const float* row = xb + (size_t)(cbase + kk) * d.T_in;
-            const int ti = d.in_stride * (t0 + 4 * u) + shift;
-            rb[i] = load_x4(row, ti, d.T_in, d.in_stride, d.in_relu);
+                for (int i = 0; i < B_F4; ++i) {
+                    const int idx = tid + i * 256;
+                    const int kk = idx / (BN / 4), u = idx % (BN / 4);
+                    const F4U v = *reinterpret_cast<const F4U*>(xb + (size_t)kk * d.T_in + (lo + 4 * u));
+                    rb[i] = f32x4{v.x, v.y, v.z, v.w};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_F4; ++i) {
+                    const int idx = tid + i * 256;
+                    const int kk = idx / (BN / 4), u = idx % (BN / 4);
+                    const float* p = xb + (size_t)kk * d.T_in + (lo + 8 * u);
+                    const F4U v0 = *reinterpret_cast<const F4U*>(p);
+                    const F4U v1 = *reinterpret_cast<const F4U*>(p + 4);
+                    rb[i] = f32x4{v0.x, v0.z, v1.x, v1.z};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int idx = tid + i * 256;
+                const int kk = idx / (BN / 4), u = idx % (BN / 4);
+                const float* row = xb + (size_t)kk * d.T_in;
+                const int ti = lo + d.in_stride * 4 * u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tt = ti + d.in_stride * e;
+                    rb[i][e] = (tt >= 0 && tt < d.T_in) ? row[tt] : 0.0f;
+                }
+            }
         }
     };
 
@@ -224,7 +213,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
         for (int i = 0; i < B_F4; ++i) {
             const int idx = tid + i * 256;
             const int kk = idx / (BN / 4), u = idx % (BN / 4);
-            *reinterpret_cast<f32x4*>(Bb + kk * BN + 4 * u) = rb[i];
+            f32x4 v = rb[i];
+            if (d.in_relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+            }
+            *reinterpret_cast<f32x4*>(Bb + kk * BN + 4 * u) = v;
         }
     };
 
@@ -236,51 +230,95 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.0f;
 
-    int ld_tap = next_tap(-1), ld_kc = 0;
-    if (nsteps > 0) {
-        load_tiles(ld_tap, ld_kc);
-        store_tiles(0);
-        ld_kc += BK;
-        if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
-    }
-    __syncthreads();
+    // one k-step (2 channels) of operand fragments: lanes 0-31 take channel 2ks, lanes 32-63 2ks+1
+    auto read_frags = [&](const float* Ab, const float* Bb, int ks, float (&av)[MT], float (&bv)[NT]) {
+        const int kk = 2 * ks + lhi;
+        if constexpr (MT == 2) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(Ab + kk * BM);
+            av[0] = t[0]; av[1] = t[1];
+        } else {
+            av[0] = Ab[kk * BM];
+        }
+        if constexpr (NT == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(Bb + kk * BN);
+            bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+        } else if constexpr (NT == 2) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(Bb + kk * BN);
+            bv[0] = t[0]; bv[1] = t[1];
+        } else {
+            bv[0] = Bb[kk * BN];
+        }
+    };
+    auto mma = [&](const float (&av)[MT], const float (&bv)[NT]) {
+#pragma unroll
+        for (int e = 0; e < MT; ++e)
+#pragma unroll
+            for (int f = 0; f < NT; ++f)
+                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+    };
 
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        const bool more = (s + 1 < nsteps);
-        if (more) {
-            load_tiles(ld_tap, ld_kc);  // global loads in flight under the MFMAs below
+    // The K loop exists twice: a straight-line version for blocks whose active taps are all
+    // interior (no bounds checks, no divergent code, loads never wait on each other) and a
+    // generic one for the few blocks that touch the left/right edge of the signal.
+    // Software pipeline per K-step (one barrier each):
+    //   MFMAs of the first half  |  mid: tile k+1 registers -> LDS (other buffer), then the
+    //   global loads of tile k+2 are issued into the same registers  |  MFMAs of the second half
+    // so the LDS writes retire under the second half and a global load has a whole K-step to
+    // land.  The barrier is a raw s_barrier behind lgkmcnt(0) only: __syncthreads() would also
+    // drain vmcnt, i.e. wait for the loads that were just issued.
+    auto k_loop = [&](auto fast_tag) {
+        int ld_tap = next_tap(-1), ld_kc = 0;
+        auto advance = [&]() {
             ld_kc += BK;
             if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
+        };
+        if (nsteps > 0) {
+            load_tiles(fast_tag, ld_tap, ld_kc);
+            advance();
+            store_tiles(0);
+            if (nsteps > 1) { load_tiles(fast_tag, ld_tap, ld_kc); advance(); }
         }
-        const float* Ab = As + buf * BK * BM + wm * (MT * 32) + MT * l31;
-        const float* Bb = Bs + buf * BK * BN + wn * (NT * 32) + NT * l31;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            const float* Ab = As + buf * BK * BM + wm * (MT * 32) + MT * l31;
+            const float* Bb = Bs + buf * BK * BN + wn * (NT * 32) + NT * l31;
+            // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run;
+            // sched_barrier pins that order (hipcc otherwise sinks the reads next to their use)
+            float a0[MT], b0[NT], a1[MT], b1[NT];
+            read_frags(Ab, Bb, 0, a0, b0);
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int kk = 2 * ks + lhi;
-            float av[MT], bv[NT];
-            if constexpr (MT == 2) {
-                const f32x2 t = *reinterpret_cast<const f32x2*>(Ab + kk * BM);
-                av[0] = t[0]; av[1] = t[1];
-            } else {
-                av[0] = Ab[kk * BM];
+            for (int ks = 0; ks < BK / 2; ks += 2) {
+                read_frags(Ab, Bb, ks + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < BK / 2) read_frags(Ab, Bb, ks + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == BK / 4 - 2) {  // middle of the K-step
+                    if (s + 1 < nsteps) {
+                        store_tiles(buf ^ 1);
+                        if (s + 2 < nsteps) { load_tiles(fast_tag, ld_tap, ld_kc); advance(); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if constexpr (NT == 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(Bb + kk * BN);
-                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
-            } else {
-                const f32x2 t = *reinterpret_cast<const f32x2*>(Bb + kk * BN);
-                bv[0] = t[0]; bv[1] = t[1];
-            }
-#pragma unroll
-            for (int e = 0; e < MT; ++e)
-#pragma unroll
-                for (int f = 0; f < NT; ++f)
-                    acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // own LDS writes done (lgkmcnt(0)); loads stay in flight
+            __builtin_amdgcn_s_barrier();
         }
-        if (more) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+    bool all_interior = true;
+    for (int j = 0; j < d.ntaps; ++j) {
+        if (!((act >> j) & 1u)) continue;
+        const int lo = d.in_stride * t0 + d.tap_shift[j];
+        const int hi = d.in_stride * (t0 + BN - 1) + d.tap_shift[j] + (d.in_stride - 1);  // last element touched
+        all_interior = all_interior && (lo >= 0) && (hi < d.T_in);
     }
+    if (all_interior) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // ------------------------------------------------------------------ epilogue
     const int tb = t0 + wn * (NT * 32) + NT * l31;  // first of this lane's NT output times
@@ -493,14 +531,17 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
         const int mt = (rows <= 64 && d.epilogue != VQW_EPI_GATE) ? 1 : 2;
         // wide time tiles when there is enough work to fill the chip with them
         const long blocks_wide = (long)vqw_cdiv(rows, 64 * mt) * vqw_cdiv(d.T_out, 256) * d.B;
-        const int ntile = (d.T_out >= 256 && blocks_wide >= 512) ? 4 : 2;
+        (void)blocks_wide;
+        const int ntile = 2;
         tile = 10 * mt + ntile;
     }
     switch (tile) {
         case 24: return launch_cfg<2, 4>(a, st);
         case 22: return launch_cfg<2, 2>(a, st);
+        case 21: return launch_cfg<2, 1>(a, st);
         case 14: return launch_cfg<1, 4>(a, st);
         case 12: return launch_cfg<1, 2>(a, st);
+        case 11: return launch_cfg<1, 1>(a, st);
         default: return vqw_set_error("vqw_conv_gemm: unsupported tile %d", tile);
     }
 }

@@ -10,6 +10,8 @@
 // permuted identically for A and B, so the sum is unchanged).  Row stride 36 floats makes
 // those reads bank-conflict-free.  Partial tiles are combined with global fp32 atomics
 // (128-byte row segments per wave instruction).
+#include <type_traits>
+
 #include "vqw_common.h"
 
 namespace {
@@ -85,40 +87,68 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
     f32x4 rp[P_F4], rq[Q_F4];
 
-    auto load_tiles = [&](int t0) {
+    // Block-uniform classification: a block is FAST when its whole dw tile is inside
+    // [0,Cp) x [0,Qtot), its time range is whole K-steps and every p window is inside [0,T_p).
+    const int p_lo = d.p_stride * tbeg + shift;
+    const int p_hi = d.p_stride * (tbeg + nsteps * BT - 1) + shift + (d.p_stride - 1);
+    const bool fast = (c0 + BM <= d.Cp) && (o0 + BN <= Qtot) && (tbeg + nsteps * BT <= tend) &&
+                      (p_lo >= 0) && (p_hi < d.T_p) && (o0 + BN <= d.Q0 || o0 >= d.Q0);
+
+    auto load_tiles = [&](auto fast_tag, int t0) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        if constexpr (FAST) {
+            const float* pb = d.p + ((size_t)b * d.Cp + c0) * d.T_p + (d.p_stride * t0 + shift);
+            const float* qb = (o0 < d.Q0) ? d.q0 + ((size_t)b * d.Q0 + o0) * d.T_q + t0
+                                          : d.q1 + ((size_t)b * d.Q1 + (o0 - d.Q0)) * d.T_q + t0;
 #pragma unroll
-        for (int i = 0; i < P_F4; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (BT / 4), tq = idx % (BT / 4);
-            const int c = c0 + row;
-            const int t = t0 + 4 * tq;
-            if (c < d.Cp && t < tend) {
-                const float* rowp = d.p + ((size_t)b * d.Cp + c) * d.T_p;
-                rp[i] = wg_load4(rowp, d.p_stride * t + shift, d.T_p, d.p_stride, d.p_relu);
-            } else {
-                rp[i] = f32x4{0, 0, 0, 0};
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < Q_F4; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / (BT / 4), tq = idx % (BT / 4);
-            const int o = o0 + row;
-            const int t = t0 + 4 * tq;
-            if (o < Qtot && t < tend) {
-                const float* rowp = (o < d.Q0) ? d.q0 + ((size_t)b * d.Q0 + o) * d.T_q
-                                               : d.q1 + ((size_t)b * d.Q1 + (o - d.Q0)) * d.T_q;
-                f32x4 v;
-                if (t + 3 < tend) {
-                    const F4U u = *reinterpret_cast<const F4U*>(rowp + t);  // rows need only 4-byte alignment
-                    v = {u.x, u.y, u.z, u.w};
+            for (int i = 0; i < P_F4; ++i) {
+                const int idx = tid + i * 256;
+                const int row = idx / (BT / 4), tq = idx % (BT / 4);
+                if (d.p_stride == 1) {
+                    const F4U v = *reinterpret_cast<const F4U*>(pb + (size_t)row * d.T_p + 4 * tq);
+                    rp[i] = f32x4{v.x, v.y, v.z, v.w};
                 } else {
+                    const float* pp = pb + (size_t)row * d.T_p + 8 * tq;
+                    const F4U v0 = *reinterpret_cast<const F4U*>(pp);
+                    const F4U v1 = *reinterpret_cast<const F4U*>(pp + 4);
+                    rp[i] = f32x4{v0.x, v0.z, v1.x, v1.z};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < Q_F4; ++i) {
+                const int idx = tid + i * 256;
+                const int row = idx / (BT / 4), tq = idx % (BT / 4);
+                const F4U v = *reinterpret_cast<const F4U*>(qb + (size_t)row * d.T_q + 4 * tq);
+                rq[i] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < P_F4; ++i) {
+                const int idx = tid + i * 256;
+                const int row = idx / (BT / 4), tq = idx % (BT / 4);
+                const int c = c0 + row;
+                const int t = t0 + 4 * tq;
+                if (c < d.Cp && t < tend) {
+                    const float* rowp = d.p + ((size_t)b * d.Cp + c) * d.T_p;
+                    rp[i] = wg_load4(rowp, d.p_stride * t + shift, d.T_p, d.p_stride, 0);
+                } else {
+                    rp[i] = f32x4{0, 0, 0, 0};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < Q_F4; ++i) {
+                const int idx = tid + i * 256;
+                const int row = idx / (BT / 4), tq = idx % (BT / 4);
+                const int o = o0 + row;
+                const int t = t0 + 4 * tq;
+                f32x4 v = f32x4{0, 0, 0, 0};
+                if (o < Qtot && t < tend) {
+                    const float* rowp = (o < d.Q0) ? d.q0 + ((size_t)b * d.Q0 + o) * d.T_q
+                                                   : d.q1 + ((size_t)b * d.Q1 + (o - d.Q0)) * d.T_q;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (t + e < tend) ? rowp[t + e] : 0.0f;
                 }
                 rq[i] = v;
-            } else {
-                rq[i] = f32x4{0, 0, 0, 0};
             }
         }
     };
@@ -128,7 +158,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < P_F4; ++i) {
             const int idx = tid + i * 256;
-            *reinterpret_cast<f32x4*>(Pb + (idx / (BT / 4)) * LDT + 4 * (idx % (BT / 4))) = rp[i];
+            f32x4 v = rp[i];
+            if (d.p_relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+            }
+            *reinterpret_cast<f32x4*>(Pb + (idx / (BT / 4)) * LDT + 4 * (idx % (BT / 4))) = v;
         }
 #pragma unroll
         for (int i = 0; i < Q_F4; ++i) {
@@ -145,37 +180,59 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.0f;
 
-    if (nsteps > 0) {
-        load_tiles(tbeg);
-        store_tiles(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        const bool more = (s + 1 < nsteps);
-        if (more) load_tiles(tbeg + (s + 1) * BT);
-        const float* Pb = Ps + buf * BM * LDT + (wm * MT * 32 + l31) * LDT + 4 * lhi;
-        const float* Qb = Qs + buf * BN * LDT + (wn * NT * 32 + l31) * LDT + 4 * lhi;
+    auto read_frags = [&](const float* Pb, const float* Qb, int kb, f32x4 (&av)[MT], f32x4 (&bv)[NT]) {
 #pragma unroll
-        for (int kb = 0; kb < BT / 8; ++kb) {
-            f32x4 av[MT], bv[NT];
+        for (int e = 0; e < MT; ++e) av[e] = *reinterpret_cast<const f32x4*>(Pb + e * 32 * LDT + kb * 8);
+#pragma unroll
+        for (int f = 0; f < NT; ++f) bv[f] = *reinterpret_cast<const f32x4*>(Qb + f * 32 * LDT + kb * 8);
+    };
+    auto mma = [&](const f32x4 (&av)[MT], const f32x4 (&bv)[NT]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < MT; ++e)
-                av[e] = *reinterpret_cast<const f32x4*>(Pb + e * 32 * LDT + kb * 8);
 #pragma unroll
-            for (int f = 0; f < NT; ++f)
-                bv[f] = *reinterpret_cast<const f32x4*>(Qb + f * 32 * LDT + kb * 8);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < MT; ++e)
-#pragma unroll
-                    for (int f = 0; f < NT; ++f)
-                        acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e][u], bv[f][u], acc[e][f], 0, 0, 0);
+                for (int f = 0; f < NT; ++f)
+                    acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e][u], bv[f][u], acc[e][f], 0, 0, 0);
+    };
+
+    // Same software pipeline as the conv engine: tile k+1 goes registers -> LDS in the middle of
+    // K-step k, the loads of tile k+2 are issued right behind it; raw s_barrier + lgkmcnt(0).
+    auto k_loop = [&](auto fast_tag) {
+        if (nsteps > 0) {
+            load_tiles(fast_tag, tbeg);
+            store_tiles(0);
+            if (nsteps > 1) load_tiles(fast_tag, tbeg + BT);
         }
-        if (more) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            const float* Pb = Ps + buf * BM * LDT + (wm * MT * 32 + l31) * LDT + 4 * lhi;
+            const float* Qb = Qs + buf * BN * LDT + (wn * NT * 32 + l31) * LDT + 4 * lhi;
+            f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+            read_frags(Pb, Qb, 0, a0, b0);
+#pragma unroll
+            for (int kb = 0; kb < BT / 8; kb += 2) {
+                read_frags(Pb, Qb, kb + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + 2 < BT / 8) read_frags(Pb, Qb, kb + 2, a0, b0);
+                if (kb == 0 && s + 1 < nsteps) {
+                    store_tiles(buf ^ 1);
+                    if (s + 2 < nsteps) load_tiles(fast_tag, tbeg + (s + 2) * BT);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    if (fast) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     if (nsteps == 0) return;
 
     float* dwt = d.dw + (size_t)tap * d.dw_tap_stride;

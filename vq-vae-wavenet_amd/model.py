@@ -81,6 +81,10 @@ class VQVAE:
         self._init_params(seed)
         self._ws = {}
         self.loss_buf = torch.zeros(4, device=self.dev)  # [CE sum, sum of min distances, -, -]
+        # per-call-site tile choices of the conv engine (10*MT+NT; 0 = library heuristic), from
+        # tools/bench_kernels.py on MI355X at B=8, T=6656: block counts are 13*2^k, so the tile
+        # that balances best over 256 CUs differs per GEMM shape
+        self.tiles = {'out': 12, 'gate_bwd': 21, 'dgrad': 21}
 
     # ------------------------------------------------------------------ parameter layout
     def _build_layout(self):
@@ -330,7 +334,7 @@ class VQVAE:
                         epilogue=K.EPI_GATE)                                              # wavenet_ops.py:104-114
             K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
                         aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
-                        epilogue=K.EPI_ACCUM_SPLIT)                                       # :132-136, wavenet.py:72-73
+                        epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])                                       # :132-136, wavenet.py:72-73
         K.conv_gemm(x0=ws['skip'], in_relu=True, w=P['post1_w'], bias=P['post1_b'], out0=ws['h1'],
                     cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T, M=S,
                     C0=S, taps=[0])                                                       # wavenet.py:80-88
@@ -408,17 +412,18 @@ class VQVAE:
             top = (l == L - 1)       # net[L] is unused by the graph: its gradient is zero
             K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
                         aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
-                        epilogue=K.EPI_GATE_BWD)
+                        epilogue=K.EPI_GATE_BWD, tile=self.tiles['gate_bwd'])
             K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
                          Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
             if not top:
                 K.rowsum(dnet, total=G['out_b'][l][S:])
             taps_b = [(ks - 1 - j) * d for j in range(ks)]
             if top:
-                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b)
+                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
+                            tile=self.tiles['dgrad'])
             else:
                 K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T,
-                            M=R, M0=0, C0=2 * R, taps=taps_b, epilogue=K.EPI_ACCUM_SPLIT)
+                            M=R, M0=0, C0=2 * R, taps=taps_b, epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['dgrad'])
             K.wgrad_gemm(p=net[l], q0=dpre, dw=G['gated_w'][l], B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
                          taps=[-(ks - 1 - j) * d for j in range(ks)])
             K.rowsum(dpre, seg_out=seg_l, total=G['gated_b'][l], seg=ratio)
