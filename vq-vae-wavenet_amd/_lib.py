@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libvqwave.so')
+LIB_PATH = os.path.join(_HERE, 'lib', os.environ.get('VQW_LIB_NAME', 'libvqwave.so'))
 MAX_TAPS = 8
 
 EPI_STORE, EPI_ACCUM_SPLIT, EPI_GATE, EPI_GATE_BWD, EPI_MASK = range(5)

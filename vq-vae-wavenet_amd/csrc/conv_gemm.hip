@@ -23,7 +23,26 @@
 
 namespace {
 
-constexpr int BK = 16;  // channels per K-step
+#ifndef VQW_BK
+#define VQW_BK 16
+#endif
+#ifndef VQW_SETPRIO
+#define VQW_SETPRIO 0
+#endif
+#ifndef VQW_SCHED
+#define VQW_SCHED 1
+#endif
+constexpr int BK = VQW_BK;  // channels per K-step
+#if VQW_SCHED
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCHED_FENCE() ((void)0)
+#endif
+#if VQW_SETPRIO
+#define MMA_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define MMA_PRIO(p) ((void)0)
+#endif
 
 struct ConvArgs {
     vqw_conv_desc d;
@@ -118,7 +137,14 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     }
     const int nsteps = nact * kchunks;
 
+    // Staging registers.  A "piece" is what one thread moves per K-step in one go: one float4
+    // of activations, or one float4 of weights (GATE: the matching filter+gate float4 pair).
+    constexpr int NA = GATE ? A_F4 / 2 : A_F4;   // weight pieces
+    constexpr int NPIECE = NA + B_F4;
+    static_assert(NPIECE <= BK / 2, "one staging piece per MFMA group");
     f32x4 ra[A_F4], rb[B_F4];
+    const __amdgpu_buffer_rsrc_t rs0 = vqw_make_rsrc(d.x0 + (size_t)b * d.C0 * d.T_in, (unsigned)d.C0 * d.T_in * 4u);
+    const __amdgpu_buffer_rsrc_t rs1 = vqw_make_rsrc(d.C1 ? d.x1 + (size_t)b * d.C1 * d.T_in : d.x0, (unsigned)(d.C1 ? d.C1 : 1) * d.T_in * 4u);
 
     auto next_tap = [&](int j) {
         ++j;
@@ -126,62 +152,49 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
         return j;
     };
 
-    // Staging loads.  Everything that decides the code path is block-uniform, so the fast
-    // path is straight-line: all global loads of a K-step issue back to back and stay in
-    // flight under the MFMAs of the previous step.
-    auto load_tiles = [&](auto fast_tag, int tap, int kc) {
+    // global -> registers, piece p of the tile (tap, kc).  Every decision is block-uniform.
+    auto piece_load = [&](auto fast_tag, int p, int tap, int kc) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        // ---- weights (columns beyond M are clamped, then zeroed: no divergent branch)
-        const float* wt = d.w + (size_t)tap * d.w_tap_stride + (size_t)kc * d.ldw;
-        if constexpr (GATE) {
-            const int kk = tid / (BM / 8), u2 = tid % (BM / 8);
-            const int g = o0 + 4 * u2;
-            const int gc = min(g, a.H - 4);
-            const float* wr = wt + (size_t)kk * d.ldw;
-            ra[0] = *reinterpret_cast<const f32x4*>(wr + gc);
-            ra[1] = *reinterpret_cast<const f32x4*>(wr + a.H + gc);
-            if (g >= a.H) { ra[0] = f32x4{0, 0, 0, 0}; ra[1] = f32x4{0, 0, 0, 0}; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_F4; ++i) {
-                const int idx = tid + i * 256;
+        if (p < NA) {  // ---- weights (columns beyond M are clamped, then zeroed: no divergent branch)
+            const float* wt = d.w + (size_t)tap * d.w_tap_stride + (size_t)kc * d.ldw;
+            const int idx = tid + p * 256;
+            if constexpr (GATE) {
+                const int kk = idx / (BM / 8), u2 = idx % (BM / 8);
+                const int g = o0 + 4 * u2;
+                const int gc = min(g, a.H - 4);
+                const float* wr = wt + (size_t)kk * d.ldw;
+                ra[2 * p] = *reinterpret_cast<const f32x4*>(wr + gc);
+                ra[2 * p + 1] = *reinterpret_cast<const f32x4*>(wr + a.H + gc);
+                if (g >= a.H) { ra[2 * p] = f32x4{0, 0, 0, 0}; ra[2 * p + 1] = f32x4{0, 0, 0, 0}; }
+            } else {
                 const int kk = idx / (BM / 4), u = idx % (BM / 4);
                 const int o = o0 + 4 * u;
                 const int oc = min(o, d.M - 4);
-                ra[i] = *reinterpret_cast<const f32x4*>(wt + (size_t)kk * d.ldw + oc);
-                if (o >= d.M) ra[i] = f32x4{0, 0, 0, 0};
+                ra[p] = *reinterpret_cast<const f32x4*>(wt + (size_t)kk * d.ldw + oc);
+                if (o >= d.M) ra[p] = f32x4{0, 0, 0, 0};
             }
-        }
-        // ---- activations (the dilated / strided window of this tap)
-        const int shift = d.tap_shift[tap];
-        const float* xb = (kc < d.C0) ? d.x0 + ((size_t)b * d.C0 + kc) * d.T_in
-                                      : d.x1 + ((size_t)b * d.C1 + (kc - d.C0)) * d.T_in;
-        const int lo = d.in_stride * t0 + shift;
-        if constexpr (FAST) {   // every active tap of this block is fully inside [0,T_in)
-            if (d.in_stride == 1) {
-#pragma unroll
-                for (int i = 0; i < B_F4; ++i) {
-                    const int idx = tid + i * 256;
-                    const int kk = idx / (BN / 4), u = idx % (BN / 4);
-                    const F4U v = *reinterpret_cast<const F4U*>(xb + (size_t)kk * d.T_in + (lo + 4 * u));
-                    rb[i] = f32x4{v.x, v.y, v.z, v.w};
+        } else {       // ---- activations (the dilated / strided window of this tap)
+            const int i = p - NA;
+            const int shift = d.tap_shift[tap];
+            const float* xb = (kc < d.C0) ? d.x0 + ((size_t)b * d.C0 + kc) * d.T_in
+                                          : d.x1 + ((size_t)b * d.C1 + (kc - d.C0)) * d.T_in;
+            const int lo = d.in_stride * t0 + shift;
+            const int idx = tid + i * 256;
+            const int kk = idx / (BN / 4), u = idx % (BN / 4);
+            if constexpr (FAST) {   // every active tap of this block is fully inside [0,T_in)
+                // one batch element per descriptor (< 4 GB); voffset = per-thread part, soffset = uniform part
+                const bool first = kc < d.C0;
+                const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+                const int soff = ((first ? kc : kc - d.C0) * d.T_in + lo) * 4;
+                if (d.in_stride == 1) {
+                    rb[i] = vqw_buf_load4(rs, (kk * d.T_in + 4 * u) * 4, soff);
+                } else {
+                    const int vo = (kk * d.T_in + 8 * u) * 4;
+                    const f32x4 v0 = vqw_buf_load4(rs, vo, soff);
+                    const f32x4 v1 = vqw_buf_load4(rs, vo + 16, soff);
+                    rb[i] = f32x4{v0[0], v0[2], v1[0], v1[2]};
                 }
             } else {
-#pragma unroll
-                for (int i = 0; i < B_F4; ++i) {
-                    const int idx = tid + i * 256;
-                    const int kk = idx / (BN / 4), u = idx % (BN / 4);
-                    const float* p = xb + (size_t)kk * d.T_in + (lo + 8 * u);
-                    const F4U v0 = *reinterpret_cast<const F4U*>(p);
-                    const F4U v1 = *reinterpret_cast<const F4U*>(p + 4);
-                    rb[i] = f32x4{v0.x, v0.z, v1.x, v1.z};
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_F4; ++i) {
-                const int idx = tid + i * 256;
-                const int kk = idx / (BN / 4), u = idx % (BN / 4);
                 const float* row = xb + (size_t)kk * d.T_in;
                 const int ti = lo + d.in_stride * 4 * u;
 #pragma unroll
@@ -193,24 +206,24 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
         }
     };
 
-    auto store_tiles = [&](int buf) {
-        float* Ab = As + buf * BK * BM;
-        float* Bb = Bs + buf * BK * BN;
-        if constexpr (GATE) {
-            const int kk = tid / (BM / 8), u2 = tid % (BM / 8);
-            float* p = Ab + kk * BM + 8 * u2;
-            *reinterpret_cast<f32x4*>(p) = f32x4{ra[0][0], ra[1][0], ra[0][1], ra[1][1]};
-            *reinterpret_cast<f32x4*>(p + 4) = f32x4{ra[0][2], ra[1][2], ra[0][3], ra[1][3]};
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_F4; ++i) {
-                const int idx = tid + i * 256;
+    // registers -> LDS, piece p
+    auto piece_store = [&](int p, int buf) {
+        if (p < NA) {
+            float* Ab = As + buf * BK * BM;
+            const int idx = tid + p * 256;
+            if constexpr (GATE) {
+                const int kk = idx / (BM / 8), u2 = idx % (BM / 8);
+                float* q = Ab + kk * BM + 8 * u2;
+                const f32x4 F = ra[2 * p], G = ra[2 * p + 1];
+                *reinterpret_cast<f32x4*>(q) = f32x4{F[0], G[0], F[1], G[1]};
+                *reinterpret_cast<f32x4*>(q + 4) = f32x4{F[2], G[2], F[3], G[3]};
+            } else {
                 const int kk = idx / (BM / 4), u = idx % (BM / 4);
-                *reinterpret_cast<f32x4*>(Ab + kk * BM + 4 * u) = ra[i];
+                *reinterpret_cast<f32x4*>(Ab + kk * BM + 4 * u) = ra[p];
             }
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
+        } else {
+            const int i = p - NA;
+            float* Bb = Bs + buf * BK * BN;
             const int idx = tid + i * 256;
             const int kk = idx / (BN / 4), u = idx % (BN / 4);
             f32x4 v = rb[i];
@@ -257,15 +270,16 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
                 acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[f], acc[e][f], 0, 0, 0);
     };
 
-    // The K loop exists twice: a straight-line version for blocks whose active taps are all
-    // interior (no bounds checks, no divergent code, loads never wait on each other) and a
-    // generic one for the few blocks that touch the left/right edge of the signal.
-    // Software pipeline per K-step (one barrier each):
-    //   MFMAs of the first half  |  mid: tile k+1 registers -> LDS (other buffer), then the
-    //   global loads of tile k+2 are issued into the same registers  |  MFMAs of the second half
-    // so the LDS writes retire under the second half and a global load has a whole K-step to
-    // land.  The barrier is a raw s_barrier behind lgkmcnt(0) only: __syncthreads() would also
-    // drain vmcnt, i.e. wait for the loads that were just issued.
+    // Software pipeline.  K-step s computes from LDS buffer s&1.  Its BK/2 MFMA groups are each
+    // followed by ONE staging piece: tile s+1 goes registers -> LDS (other buffer) and the
+    // same registers are immediately re-loaded with tile s+2, so a wave never has a long
+    // MFMA-free stretch, every global load has a whole K-step to land and the LDS writes
+    // retire under the following MFMAs.  (Measured: staging in one lump cost ~20 % of the MFMA
+    // rate because co-resident workgroups run in lockstep and all hit the lump together.)
+    // The barrier is a raw s_barrier behind lgkmcnt(0) only: __syncthreads() would also drain
+    // vmcnt, i.e. wait for the loads that were just issued.  The K loop exists twice: a
+    // straight-line version for blocks whose active taps are all interior and a generic one
+    // for the few blocks that touch the left/right edge of the signal.
     auto k_loop = [&](auto fast_tag) {
         int ld_tap = next_tap(-1), ld_kc = 0;
         auto advance = [&]() {
@@ -273,14 +287,23 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
             if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
         };
         if (nsteps > 0) {
-            load_tiles(fast_tag, ld_tap, ld_kc);
+#pragma unroll
+            for (int p = 0; p < NPIECE; ++p) piece_load(fast_tag, p, ld_tap, ld_kc);
             advance();
-            store_tiles(0);
-            if (nsteps > 1) { load_tiles(fast_tag, ld_tap, ld_kc); advance(); }
+#pragma unroll
+            for (int p = 0; p < NPIECE; ++p) piece_store(p, 0);
+            if (nsteps > 1) {
+#pragma unroll
+                for (int p = 0; p < NPIECE; ++p) piece_load(fast_tag, p, ld_tap, ld_kc);
+                advance();
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        for (int s = 0; s < nsteps; ++s) {
+        // MODE 2: store tile s+1 and load tile s+2 (steady state, no conditionals around the
+        // loads so the compiler can count vmcnt exactly); 1: store only; 0: last K-step.
+        auto kstep = [&](auto mode_tag, int s) {
+            constexpr int MODE = decltype(mode_tag)::value;
             const int buf = s & 1;
             const float* Ab = As + buf * BK * BM + wm * (MT * 32) + MT * l31;
             const float* Bb = Bs + buf * BK * BN + wn * (NT * 32) + NT * l31;
@@ -291,24 +314,49 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ks += 2) {
                 read_frags(Ab, Bb, ks + 1, a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
+                SCHED_FENCE();
+                MMA_PRIO(1);
                 mma(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks + 2 < BK / 2) read_frags(Ab, Bb, ks + 2, a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks == BK / 4 - 2) {  // middle of the K-step
-                    if (s + 1 < nsteps) {
-                        store_tiles(buf ^ 1);
-                        if (s + 2 < nsteps) { load_tiles(fast_tag, ld_tap, ld_kc); advance(); }
+                MMA_PRIO(0);
+                SCHED_FENCE();
+                if constexpr (MODE >= 1) {
+                    if (ks < NPIECE) {
+#ifndef VQW_ABL_NOSTORE
+                        piece_store(ks, buf ^ 1);
+#endif
+                        SCHED_FENCE();  // keep the re-load behind the store: same registers, no copy
+#ifndef VQW_ABL_NOLOAD
+                        if constexpr (MODE == 2) piece_load(fast_tag, ks, ld_tap, ld_kc);
+#endif
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (ks + 2 < BK / 2) read_frags(Ab, Bb, ks + 2, a0, b0);
+                SCHED_FENCE();
+                MMA_PRIO(1);
+                mma(a1, b1);
+                MMA_PRIO(0);
+                SCHED_FENCE();
+                if constexpr (MODE >= 1) {
+                    if (ks + 1 < NPIECE) {
+#ifndef VQW_ABL_NOSTORE
+                        piece_store(ks + 1, buf ^ 1);
+#endif
+                        SCHED_FENCE();
+#ifndef VQW_ABL_NOLOAD
+                        if constexpr (MODE == 2) piece_load(fast_tag, ks + 1, ld_tap, ld_kc);
+#endif
+                    }
+                }
+                SCHED_FENCE();
             }
+            if constexpr (MODE == 2) advance();
             __builtin_amdgcn_s_waitcnt(0xC07F);  // own LDS writes done (lgkmcnt(0)); loads stay in flight
             __builtin_amdgcn_s_barrier();
-        }
+        };
+        int s = 0;
+        for (; s + 2 < nsteps; ++s) kstep(std::integral_constant<int, 2>{}, s);
+        if (s + 1 < nsteps) { kstep(std::integral_constant<int, 1>{}, s); ++s; }
+        if (s < nsteps) kstep(std::integral_constant<int, 0>{}, s);
     };
     bool all_interior = true;
     for (int j = 0; j < d.ntaps; ++j) {

@@ -15,6 +15,21 @@ struct __attribute__((packed, aligned(4))) F4U {
     float x, y, z, w;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+// Raw buffer access: a 16-byte load from an address that is only 4-byte aligned (the dilated
+// window of a conv tap starts at t0 - j*d) is ONE buffer_load_dwordx4 this way; through a plain
+// pointer hipcc splits it into four global_load_dword (alignment 4), i.e. 4x the TA work.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vqw_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 vqw_buf_load4(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+#endif
+
 int vqw_set_error(const char* fmt, ...);
 
 #define VQW_CHECK(cond, ...)                           \

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int shift = d.tap_shift[tap];
 
     f32x4 rp[P_F4], rq[Q_F4];
+    const __amdgpu_buffer_rsrc_t rsp = vqw_make_rsrc(d.p + (size_t)b * d.Cp * d.T_p, (unsigned)d.Cp * d.T_p * 4u);
+    const __amdgpu_buffer_rsrc_t rsq0 = vqw_make_rsrc(d.q0 + (size_t)b * d.Q0 * d.T_q, (unsigned)d.Q0 * d.T_q * 4u);
+    const __amdgpu_buffer_rsrc_t rsq1 = vqw_make_rsrc(d.Q1 ? d.q1 + (size_t)b * d.Q1 * d.T_q : d.q0, (unsigned)(d.Q1 ? d.Q1 : 1) * d.T_q * 4u);
 
     // Block-uniform classification: a block is FAST when its whole dw tile is inside
     // [0,Cp) x [0,Qtot), its time range is whole K-steps and every p window is inside [0,T_p).
@@ -94,38 +97,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const bool fast = (c0 + BM <= d.Cp) && (o0 + BN <= Qtot) && (tbeg + nsteps * BT <= tend) &&
                       (p_lo >= 0) && (p_hi < d.T_p) && (o0 + BN <= d.Q0 || o0 >= d.Q0);
 
-    auto load_tiles = [&](auto fast_tag, int t0) {
+    // One staging piece = one float4 per thread: pieces [0,P_F4) belong to p, the rest to q.
+    constexpr int NPIECE = P_F4 + Q_F4;
+    static_assert(NPIECE <= BT / 2, "one staging piece per 4-MFMA group");
+    auto piece_load = [&](auto fast_tag, int pc, int t0) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        if constexpr (FAST) {
-            const float* pb = d.p + ((size_t)b * d.Cp + c0) * d.T_p + (d.p_stride * t0 + shift);
-            const float* qb = (o0 < d.Q0) ? d.q0 + ((size_t)b * d.Q0 + o0) * d.T_q + t0
-                                          : d.q1 + ((size_t)b * d.Q1 + (o0 - d.Q0)) * d.T_q + t0;
-#pragma unroll
-            for (int i = 0; i < P_F4; ++i) {
-                const int idx = tid + i * 256;
-                const int row = idx / (BT / 4), tq = idx % (BT / 4);
+        const int i = pc < P_F4 ? pc : pc - P_F4;
+        const int idx = tid + i * 256;
+        const int row = idx / (BT / 4), tq = idx % (BT / 4);
+        if (pc < P_F4) {
+            if constexpr (FAST) {
+                const int soff = (c0 * d.T_p + d.p_stride * t0 + shift) * 4;   // block-uniform part
                 if (d.p_stride == 1) {
-                    const F4U v = *reinterpret_cast<const F4U*>(pb + (size_t)row * d.T_p + 4 * tq);
-                    rp[i] = f32x4{v.x, v.y, v.z, v.w};
+                    rp[i] = vqw_buf_load4(rsp, (row * d.T_p + 4 * tq) * 4, soff);
                 } else {
-                    const float* pp = pb + (size_t)row * d.T_p + 8 * tq;
-                    const F4U v0 = *reinterpret_cast<const F4U*>(pp);
-                    const F4U v1 = *reinterpret_cast<const F4U*>(pp + 4);
-                    rp[i] = f32x4{v0.x, v0.z, v1.x, v1.z};
+                    const int vo = (row * d.T_p + 8 * tq) * 4;
+                    const f32x4 v0 = vqw_buf_load4(rsp, vo, soff);
+                    const f32x4 v1 = vqw_buf_load4(rsp, vo + 16, soff);
+                    rp[i] = f32x4{v0[0], v0[2], v1[0], v1[2]};
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < Q_F4; ++i) {
-                const int idx = tid + i * 256;
-                const int row = idx / (BT / 4), tq = idx % (BT / 4);
-                const F4U v = *reinterpret_cast<const F4U*>(qb + (size_t)row * d.T_q + 4 * tq);
-                rq[i] = f32x4{v.x, v.y, v.z, v.w};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < P_F4; ++i) {
-                const int idx = tid + i * 256;
-                const int row = idx / (BT / 4), tq = idx % (BT / 4);
+            } else {
                 const int c = c0 + row;
                 const int t = t0 + 4 * tq;
                 if (c < d.Cp && t < tend) {
@@ -135,10 +126,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                     rp[i] = f32x4{0, 0, 0, 0};
                 }
             }
-#pragma unroll
-            for (int i = 0; i < Q_F4; ++i) {
-                const int idx = tid + i * 256;
-                const int row = idx / (BT / 4), tq = idx % (BT / 4);
+        } else {
+            if constexpr (FAST) {
+                const bool first = o0 < d.Q0;
+                const int soff = ((first ? o0 : o0 - d.Q0) * d.T_q + t0) * 4;
+                rq[i] = vqw_buf_load4(first ? rsq0 : rsq1, (row * d.T_q + 4 * tq) * 4, soff);
+            } else {
                 const int o = o0 + row;
                 const int t = t0 + 4 * tq;
                 f32x4 v = f32x4{0, 0, 0, 0};
@@ -152,23 +145,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             }
         }
     };
-    auto store_tiles = [&](int buf) {
-        float* Pb = Ps + buf * BM * LDT;
-        float* Qb = Qs + buf * BN * LDT;
-#pragma unroll
-        for (int i = 0; i < P_F4; ++i) {
-            const int idx = tid + i * 256;
+    auto piece_store = [&](int pc, int buf) {
+        const int i = pc < P_F4 ? pc : pc - P_F4;
+        const int idx = tid + i * 256;
+        const int off = (idx / (BT / 4)) * LDT + 4 * (idx % (BT / 4));
+        if (pc < P_F4) {
             f32x4 v = rp[i];
             if (d.p_relu) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
             }
-            *reinterpret_cast<f32x4*>(Pb + (idx / (BT / 4)) * LDT + 4 * (idx % (BT / 4))) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < Q_F4; ++i) {
-            const int idx = tid + i * 256;
-            *reinterpret_cast<f32x4*>(Qb + (idx / (BT / 4)) * LDT + 4 * (idx % (BT / 4))) = rq[i];
+            *reinterpret_cast<f32x4*>(Ps + buf * BM * LDT + off) = v;
+        } else {
+            *reinterpret_cast<f32x4*>(Qs + buf * BN * LDT + off) = rq[i];
         }
     };
 
@@ -186,28 +175,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int f = 0; f < NT; ++f) bv[f] = *reinterpret_cast<const f32x4*>(Qb + f * 32 * LDT + kb * 8);
     };
-    auto mma = [&](const f32x4 (&av)[MT], const f32x4 (&bv)[NT]) {
+    auto mma_u = [&](const f32x4 (&av)[MT], const f32x4 (&bv)[NT], int u) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int e = 0; e < MT; ++e)
 #pragma unroll
-            for (int e = 0; e < MT; ++e)
-#pragma unroll
-                for (int f = 0; f < NT; ++f)
-                    acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e][u], bv[f][u], acc[e][f], 0, 0, 0);
+            for (int f = 0; f < NT; ++f)
+                acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e][u], bv[f][u], acc[e][f], 0, 0, 0);
     };
 
-    // Same software pipeline as the conv engine: tile k+1 goes registers -> LDS in the middle of
-    // K-step k, the loads of tile k+2 are issued right behind it; raw s_barrier + lgkmcnt(0).
+    // Same software pipeline as the conv engine: after every group of MT*NT MFMAs one staging
+    // piece moves tile s+1 registers -> LDS (other buffer) and re-loads the registers with
+    // tile s+2; raw s_barrier behind lgkmcnt(0) only.
     auto k_loop = [&](auto fast_tag) {
         if (nsteps > 0) {
-            load_tiles(fast_tag, tbeg);
-            store_tiles(0);
-            if (nsteps > 1) load_tiles(fast_tag, tbeg + BT);
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) piece_load(fast_tag, pc, tbeg);
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) piece_store(pc, 0);
+            if (nsteps > 1) {
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc) piece_load(fast_tag, pc, tbeg + BT);
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
-        for (int s = 0; s < nsteps; ++s) {
+        auto kstep = [&](auto mode_tag, int s) {
+            constexpr int MODE = decltype(mode_tag)::value;   // 2: store+load, 1: store, 0: none
             const int buf = s & 1;
+            const int t2 = tbeg + (s + 2) * BT;
             const float* Pb = Ps + buf * BM * LDT + (wm * MT * 32 + l31) * LDT + 4 * lhi;
             const float* Qb = Qs + buf * BN * LDT + (wn * NT * 32 + l31) * LDT + 4 * lhi;
             f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
@@ -215,21 +210,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int kb = 0; kb < BT / 8; kb += 2) {
                 read_frags(Pb, Qb, kb + 1, a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kb + 2 < BT / 8) read_frags(Pb, Qb, kb + 2, a0, b0);
-                if (kb == 0 && s + 1 < nsteps) {
-                    store_tiles(buf ^ 1);
-                    if (s + 2 < nsteps) load_tiles(fast_tag, tbeg + (s + 2) * BT);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_u(a0, b0, u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int g = kb * 4 + u;          // 4-MFMA group index inside the K-step
+                    if constexpr (MODE >= 1) {
+                        if ((g & 1) == 0 && (g >> 1) < NPIECE) {
+                            piece_store(g >> 1, buf ^ 1);
+                            __builtin_amdgcn_sched_barrier(0);  // re-load behind the store: same registers
+                            if constexpr (MODE == 2) piece_load(fast_tag, g >> 1, t2);
+                        }
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                mma(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
+                if (kb + 2 < BT / 8) read_frags(Pb, Qb, kb + 2, a0, b0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_u(a1, b1, u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int g = (kb + 1) * 4 + u;
+                    if constexpr (MODE >= 1) {
+                        if ((g & 1) == 0 && (g >> 1) < NPIECE) {
+                            piece_store(g >> 1, buf ^ 1);
+                            __builtin_amdgcn_sched_barrier(0);  // re-load behind the store: same registers
+                            if constexpr (MODE == 2) piece_load(fast_tag, g >> 1, t2);
+                        }
+                    }
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
-        }
+        };
+        int s = 0;
+        for (; s + 2 < nsteps; ++s) kstep(std::integral_constant<int, 2>{}, s);
+        if (s + 1 < nsteps) { kstep(std::integral_constant<int, 1>{}, s); ++s; }
+        if (s < nsteps) kstep(std::integral_constant<int, 0>{}, s);
     };
     if (fast) k_loop(std::true_type{});
     else k_loop(std::false_type{});
@@ -267,8 +284,8 @@ extern "C" int vqw_wgrad_gemm(const vqw_wgrad_desc* dp, vqw_stream_t s) {
     const int tiles = a.n_ct * a.n_ot * d.ntaps;
     int chunks = d.splits;
     if (chunks <= 0) {
-        // aim for ~3 resident blocks per CU over the whole chip
-        chunks = vqw_cdiv(768, tiles * d.B);
+        // aim for ~6 blocks per CU over the whole chip (measured best on MI355X: bench_kernels.py)
+        chunks = vqw_cdiv(1536, tiles * d.B);
         const int max_chunks = vqw_cdiv(d.T_q, 4 * BT);
         if (chunks > max_chunks) chunks = max_chunks;
         if (chunks < 1) chunks = 1;
