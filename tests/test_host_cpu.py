@@ -1,0 +1,129 @@
+"""CPU tests of the host-side mirror: parameter inventory under the reference's variable names,
+LR schedule, data pipeline, CLI surface and the data-parallel gradient exchange (gloo, world 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parameter_inventory_matches_reference_names_and_count(pkg):
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    model = pkg.model.VQVAE(m, w, 109, device='cpu', seed=0)
+    ref = M.init_params(m, w, 109, seed=0)
+    mine = model.named_parameters()
+    assert list(sorted(mine)) == list(sorted(ref))
+    for k in ref:
+        assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+    trainable = sum(v.numel() for k, v in mine.items() if M.is_trainable(k))
+    assert trainable == 35151104 == model.n_flat
+    assert model.receptive_field == 6170                  # wavenet.py:16-17
+    # initialiser ranges (model.py:26,49; wavenet_ops.py:69)
+    assert abs(float(mine['embedding/embedding'].abs().max()) - 1.7 * (3 / 512) ** 0.5) < 2e-3
+    assert float(mine['decoder/preprocess/kernel'].abs().max()) <= (3 / 32) ** 0.5 + 1e-6
+    assert float(mine['decoder/cycle_1/layer_1/gated/bias'].abs().max()) == 0.0
+    assert float(mine['encoder/batch_normalization/gamma'].min()) == 1.0
+
+
+def test_load_named_roundtrip_and_ema(pkg):
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    m.update(k=32, latent_dim=16, speaker_embedding=16, encoder_filters=48)
+    w.update(dilation_rates=[1, 2], num_cycles=1, num_cycle_layers=2, dilation_filters=32, skip_filters=64,
+             residual_filters=32, preprocess={"kernel_size": 32, "filters": 32})
+    P = M.init_params(m, w, 7, seed=3, randomize_all=True)
+    model = pkg.model.VQVAE(m, w, 7, device='cpu', seed=0)
+    model.load_named(P)
+    back = model.named_parameters()
+    for k, v in P.items():
+        assert torch.equal(back[k], v), k
+    ema = model.named_parameters(ema=True)
+    assert torch.equal(ema['decoder/postprocess1/local_condition/kernel'], P['decoder/postprocess1/local_condition/kernel'])
+    with pytest.raises(KeyError):
+        model.load_named({'speaker_embedding': P['speaker_embedding']})
+    assert model.lr_at(0) == 8e-5 and model.lr_at(80000) == 6e-5 and model.lr_at(10 ** 7) == 8e-6
+    with pytest.raises(NotImplementedError):
+        pkg.model.VQVAE(dict(m, encoder='2019'), w, 7, device='cpu')
+    with pytest.raises(ValueError):
+        model._workspace(2, 100)       # length must be a multiple of 64 (Encoder_64)
+
+
+def _worker(rank, world, port, q):
+    import importlib
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    pkg = importlib.import_module('vq-vae-wavenet_amd')
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    sync = pkg.parallel.GradAllReduce(flat)
+    sync.bucket_ready(600, 1000)       # "decoder" bucket first, as in backward
+    sync.bucket_ready(0, 600)
+    w = sync.finish()
+    q.put((rank, w, flat.clone()))
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.arange(1000, dtype=torch.float32) * 3          # (1 + 2) * base
+    for rank, w, flat in res:
+        assert w == 2
+        assert torch.equal(flat, want)
+        assert torch.equal(flat / w, torch.arange(1000, dtype=torch.float32) * 1.5)   # the averaged gradient
+
+
+def test_wav_dataset_and_speaker_map(pkg, tmp_path):
+    from scipy.io import wavfile
+    root = tmp_path / 'data'
+    (root / 'VCTK-Corpus' / 'wav48' / 'p225').mkdir(parents=True)
+    (root / 'VCTK-Corpus' / 'wav48' / 'p226').mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    pcm16 = (rng.randn(16000 * 2) * 3000).astype(np.int16)
+    wavfile.write(str(root / 'VCTK-Corpus' / 'wav48' / 'p225' / 'p225_001.wav'), 16000, pcm16)
+    wavfile.write(str(root / 'VCTK-Corpus' / 'wav48' / 'p226' / 'p226_001.wav'), 48000,
+                  (rng.randn(48000 * 2) * 3000).astype(np.int16))
+    wavfile.write(str(root / 'VCTK-Corpus' / 'wav48' / 'p226' / 'short.wav'), 16000, pcm16[:100])
+    (root / 'vctk_train.txt').write_text('p225/p225_001.wav\np226/p226_001.wav\np226/short.wav\n')
+    (root / 'vctk_speakers.txt').write_text('p225, 0\np226, 1\n')
+    ds = pkg.data.VCTK(4, 6656, relative_path=str(root) + '/', device='cpu', seed=1)
+    assert ds.num_speakers == 2 and ds.speaker_to_int == {'p225': 0, 'p226': 1}
+    x, spk = ds.next()
+    assert x.shape == (4, 6656) and x.dtype == torch.float32 and spk.dtype == torch.int64
+    assert float(x.abs().max()) <= 1.0 and set(spk.tolist()) <= {0, 1}
+    direct = ds._read('p225/p225_001.wav')
+    np.testing.assert_array_equal(direct, ((pcm16.astype(np.float32) + 0.5) / 32767.5).astype(np.float32))
+    assert len(ds._read('p226/p226_001.wav')) == 32000                  # 48 kHz -> 16 kHz
+    syn = pkg.data.Synthetic(2, 512, num_speakers=10, seed=1234, device='cpu')
+    xs, ss = syn.next()
+    xo, so, _ = M.synthetic_batch(2, 512, 10, 1234)
+    assert torch.equal(xs, xo[:, :, 0]) and torch.equal(ss, so)           # same segments as the oracle / bench
+
+
+def test_cli_surface_matches_reference_flags():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'train.py'), '-h'], text=True)
+    for flag in ('-dataset', '-length', '-step', '-batch', '-interval', '-restore', '-save', '-params'):
+        assert flag in out
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'generate.py'), '-h'], text=True)
+    for flag in ('-restore', '-audio', '-speakers', '-mode', '-params'):
+        assert flag in out
+    m = __import__('json').load(open(os.path.join(ROOT, 'model_parameters.json')))
+    w = __import__('json').load(open(os.path.join(ROOT, 'wavenet_parameters.json')))
+    assert m['encoder'] == '64' and m['k'] == 512 and m['beta'] == 0.25 and m['wavenet_parameters'] == 'wavenet_parameters.json'
+    assert len(w['dilation_rates']) == w['num_cycles'] * w['num_cycle_layers'] == 30

@@ -77,6 +77,7 @@ class VQVAE:
         self.receptive_field = sum(self.dil) * (self.ks - 1) + 1 + self.pre_k - 1  # wavenet.py:16-17
         self.schedule = [(int(k), float(v)) for k, v in model_cfg['learning_rate_schedule'].items()]
         self.global_step = 0
+        self.grad_sync = None   # parallel.GradAllReduce when training data-parallel
         self._build_layout()
         self._init_params(seed)
         self._ws = {}
@@ -437,6 +438,8 @@ class VQVAE:
         # ---- local condition (wavenet_ops.py:93-101) -> d cond
         K.wgrad_gemm(p=ws['cond'], q0=dce, dw=G['cond_w'], B=B, T_q=Tz, T_p=Tz, Cp=self.Cc, Q0=self.Mall, taps=[0])
         K.conv_gemm(x0=dce, w=Tt['cond_w'], out0=ws['dcond'], B=B, T_in=Tz, T_out=Tz, M=self.Cc, C0=self.Mall, taps=[0])
+        if self.grad_sync is not None:      # decoder gradients are final: exchange them under the encoder backward
+            self.grad_sync.bucket_ready(self.seg_off['pre_w'][0], self.n_flat)
         # ---- speaker embedding + VQ (model.py:22-27, 57-74, 99-106)
         K.speaker_tile_bwd(ws['dcond'], spk, G['speaker_embedding'], dcond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs, Tz=Tz)
         nd = float(B * Tz * D)
@@ -476,6 +479,8 @@ class VQVAE:
         dsc.addcmul_(self.bn_mean, G['bn_beta'], value=-1.0)         # shift = beta - mean*scale
         torch.mul(dsc, torch.rsqrt(self.bn_var + BN_EPS), out=dsc)
         G['bn_gamma'] += dsc
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(0, self.seg_off['pre_w'][0])
 
     # ------------------------------------------------------------------ optimiser
     def lr_at(self, step):
@@ -495,12 +500,12 @@ class VQVAE:
         self.global_step = t
         return lr
 
-    def train_step(self, x, spk, allreduce=None):
-        """One sess.run(train_op) (train.py:104-114).  `allreduce(flat_grad)` sums gradients
-        over data-parallel ranks (RCCL); it returns the world size."""
+    def train_step(self, x, spk):
+        """One sess.run(train_op) (train.py:104-114).  With self.grad_sync set (data parallel)
+        the flat gradient is sum-all-reduced over RCCL in two overlapped buckets and averaged."""
         ws = self.forward(x, spk)
         self.backward(x, spk, ws)
-        world = allreduce(self.grad) if allreduce is not None else 1
+        world = self.grad_sync.finish() if self.grad_sync is not None else 1
         self.apply_gradients(1.0 / world)
         return ws
 

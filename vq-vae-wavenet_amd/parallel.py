@@ -1,0 +1,40 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL (torch.distributed 'nccl') sum
+all-reduce of the flat fp32 gradient buffer over xGMI, in buckets that are launched on a side
+stream as soon as backward has finished writing them, so the exchange of the decoder gradients
+(81 MB of 140.6 MB) overlaps the encoder backward.  The reference has no multi-GPU code
+(SURVEY.md 2.1); training shards over batch, all losses are means, BN uses moving statistics,
+so averaging the per-rank gradients reproduces the full-batch step.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradAllReduce:
+    def __init__(self, flat_grad, group=None):
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.pending = []
+
+    def bucket_ready(self, lo, hi):
+        """flat[lo:hi] holds final local gradients: start summing it across ranks."""
+        if self.world == 1 or hi <= lo:
+            return
+        view = self.flat[lo:hi]
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Wait for all buckets; returns the world size (the caller scales by 1/world)."""
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        return self.world
