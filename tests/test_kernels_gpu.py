@@ -361,3 +361,40 @@ def test_rowsum_transpose_softmax_adam(K):
         K.adam_ema_step(pd, g(gr * t), md, vd, ed, lr_t=lr_t)
     close(pd, P['w'], atol=1e-6, rtol=1e-6, what='adam param')
     close(ed, st['ema']['w'], atol=1e-6, rtol=1e-6, what='ema')
+
+
+# ----------------------------------------------------------------------------- reference-named op surface
+def test_reference_op_surface(pkg):
+    O = pkg.ops
+    B, T, R_, S_, Cc, Tz = 2, 512, 32, 64, 32, 8
+    x = rnd(B, T, 1, seed=1, s=0.3)
+    assert np.array_equal(O.mu_law_encode(g(x), to_int=True).cpu().numpy(), R.mu_law_encode_np(x.numpy(), to_int=True))
+    np.testing.assert_allclose(O.mu_law_encode(g(x)).cpu().numpy(), R.mu_law_encode_np(x.numpy()), atol=3e-7)
+    assert torch.equal(O.shift_right(g(x)).cpu(), R.shift_right(x))
+    oh = O.mu_law_encode(g(x), one_hot=True)
+    assert oh.shape == (B, T, 256) and float(oh.sum()) == B * T
+    net, cond = rnd(B, T, R_, seed=2), rnd(B, Tz, Cc, seed=3)
+    p = {'gated/kernel': rnd(3, R_, 2 * R_, seed=4, s=0.1), 'gated/bias': rnd(2 * R_, seed=5, s=0.1),
+         'gated/local_condition/kernel': rnd(1, Cc, 2 * R_, seed=6, s=0.1),
+         'skip/kernel': rnd(1, R_, S_, seed=7, s=0.1), 'skip/bias': rnd(S_, seed=8, s=0.1),
+         'residual/kernel': rnd(1, R_, R_, seed=9, s=0.1), 'residual/bias': rnd(R_, seed=10, s=0.1)}
+    pg = {k: g(v) for k, v in p.items()}
+    sk, rs = O.residual_stack(g(net), pg, 4, g(cond))
+    sk_ref, rs_ref = R.residual_stack(net, p, R_, 4, cond)
+    close(sk, sk_ref, atol=5e-5, rtol=5e-5, what='residual_stack skip')
+    close(rs, rs_ref, atol=5e-5, rtol=5e-5, what='residual_stack residual')
+    close(O.add_condition(g(net[..., :2 * R_ // 2].repeat(1, 1, 2)), g(cond), pg['gated/local_condition/kernel']),
+          R.add_condition(net.repeat(1, 1, 2), cond, p['gated/local_condition/kernel']), what='add_condition')
+    w32, b32 = rnd(32, 1, R_, seed=11, s=0.2), rnd(R_, seed=12)
+    close(O.conv1d_v2(g(x), g(w32), g(b32)), R.conv1d_v2(x, w32, b32), what='preprocess conv1d_v2')
+    v = rnd(B, R_, seed=13)
+    close(O.linear(g(v), pg['skip/kernel'], pg['skip/bias']), R.linear(v, p['skip/kernel'], p['skip/bias']), what='linear')
+    e = rnd(B, 250, 32, seed=14)
+    for fn, k, s_ in ((O.conv_3_768, 3, 1), (O.strided_conv_4_768, 4, 2), (O.linear_64, 1, 1)):
+        wk, bk = rnd(k, 32, 48, seed=15, s=0.1), rnd(48, seed=16)
+        want = R.keras_conv1d(e, wk, bk, stride=s_, padding='same', relu=fn is not O.linear_64)
+        close(fn(g(e), g(wk), g(bk)), want, what=fn.__name__)
+    h = rnd(B, 1, 16, seed=17)
+    assert torch.equal(O.concat(g(cond), g(h)).cpu(), R.concat(cond, h))
+    with pytest.raises(NotImplementedError):
+        O.conv1d_v2(g(net), pg['skip/kernel'], None, padding='SAME')

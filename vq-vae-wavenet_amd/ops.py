@@ -1,0 +1,152 @@
+"""The reference's operator surface (same names, same argument meaning) on GPU tensors.
+
+Reference: mu_law_ops.py:5-31, Decoder/WaveNet/wavenet_ops.py:9-14,59-160,
+Encoder/encoder_ops.py:46-70, Decoder/decoder_ops.py:39-43.  Tensors are channels-last
+[B,T,C] like the reference's; each op transposes to the kernels' (batch, channel, time) layout,
+calls libvqwave and transposes back (the assembled model in model.py stays in (B,C,T)
+throughout).  Where the reference creates variables implicitly (tf.get_variable) the kernel /
+bias tensors are explicit arguments with the reference's shapes: kernel [k, Cin, Cout].
+The per-sample `fast_*` ops (wavenet_ops.py:163-267) are stateful queue programs in the
+reference; their counterpart is generator.FastGenerator (vqw_ar_decode_*).
+"""
+import torch
+
+from . import _lib as L
+from . import kernels as K
+
+
+def _bct(x):
+    return x.transpose(1, 2).contiguous()
+
+
+def _btc(x):
+    return x.transpose(1, 2).contiguous()
+
+
+def mu_law_encode(x, quantization_channels=256, to_int=False, one_hot=False):
+    """mu_law_ops.py:5-15."""
+    if quantization_channels != 256:
+        raise NotImplementedError('quantization_channels must be 256 (threshold table)')
+    x = x.contiguous()
+    if to_int or one_hot:
+        y = K.mu_law_encode_i32(x)
+        if one_hot:
+            return torch.nn.functional.one_hot(y.long(), quantization_channels).float().squeeze(-2)
+        return y
+    return K.mu_law_encode_f32(x)
+
+
+def mu_law_decode(y, quantization_channels=256):
+    """mu_law_ops.py:18-31 (TF and numpy twins)."""
+    if quantization_channels != 256:
+        raise NotImplementedError('quantization_channels must be 256')
+    return K.mu_law_decode_f32(y.float().contiguous())
+
+
+mu_law_decode_np = mu_law_decode
+
+
+def shift_right(x):
+    """wavenet_ops.py:9-14."""
+    return torch.nn.functional.pad(x, (0, 0, 1, 0))[:, :-1, :].contiguous()
+
+
+def conv1d_v2(net, kernel, bias=None, padding='CAUSAL', dilations=1, stride=1):
+    """wavenet_ops.py:59-90: always left-pads d*(k-1); the `padding` argument of the reference
+    only selects VALID/SAME for the conv that follows the pad and every caller passes
+    CAUSAL/VALID."""
+    if padding.upper() not in ('CAUSAL', 'VALID'):
+        raise NotImplementedError("padding %s not used by the reference's callers" % padding)
+    B, T, Cin = net.shape
+    k, _, Cout = kernel.shape
+    if Cin == 1:
+        if dilations != 1:
+            raise NotImplementedError('Cin == 1 convs are only used with dilation 1 by the reference')
+        To = -(-T // stride)
+        out = torch.empty(B, Cout, To, device=net.device)
+        K.conv_cin1_fwd(net[:, :, 0].contiguous(), kernel.reshape(k, Cout).contiguous(), bias, out, k=k,
+                        stride=stride, offset=-(k - 1))
+        return _btc(out)
+    x = _bct(net)
+    To = -(-T // stride)
+    y = torch.empty(B, Cout, To, device=net.device)
+    L.check(L.lib().vqw_causal_conv1d_fwd(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), B, Cin, Cout,
+                                          T, k, dilations, stride, L.stream()))
+    return _btc(y)
+
+
+def linear(net, kernel, bias=None):
+    """wavenet_ops.py:147-160: one stride of a 1x1 conv on [B, Cin]."""
+    return conv1d_v2(net.unsqueeze(1), kernel, bias).squeeze(1)
+
+
+def add_condition(net, condition, kernel):
+    """wavenet_ops.py:93-101: 1x1 (no bias) on the condition + nearest-neighbour upsample-add."""
+    if condition is None:
+        return net
+    B, T, C = net.shape
+    Tz, Cc = condition.shape[1], condition.shape[2]
+    enc = torch.empty(B, C, Tz, device=net.device)
+    K.conv_gemm(x0=_bct(condition), w=kernel.reshape(Cc, C).contiguous(), out0=enc, B=B, T_in=Tz, T_out=Tz, M=C,
+                C0=Cc, taps=[0])
+    return (net.reshape(B, Tz, T // Tz, C) + _btc(enc).unsqueeze(2)).reshape(B, T, C)
+
+
+def gated_cnn(net, kernel, bias, dilations, local_condition=None, cond_kernel=None):
+    """wavenet_ops.py:104-114: causal dilated conv -> +condition -> tanh(first half)*sigmoid(second)."""
+    B, T, Cin = net.shape
+    k, _, C2 = kernel.shape
+    H = C2 // 2
+    out = torch.empty(B, H, T, device=net.device)
+    kw = {}
+    if local_condition is not None:
+        Tz, Cc = local_condition.shape[1], local_condition.shape[2]
+        enc = torch.empty(B, C2, Tz, device=net.device)
+        K.conv_gemm(x0=_bct(local_condition), w=cond_kernel.reshape(Cc, C2).contiguous(), out0=enc, B=B, T_in=Tz,
+                    T_out=Tz, M=C2, C0=Cc, taps=[0])
+        kw = dict(cond=enc, cond_T=Tz)
+    K.conv_gemm(x0=_bct(net), w=kernel.contiguous(), bias=bias, out0=out, B=B, T_in=T, T_out=T, M=C2, C0=Cin,
+                taps=[-(k - 1 - j) * dilations for j in range(k)], epilogue=K.EPI_GATE, **kw)
+    return _btc(out)
+
+
+def residual_stack(net, params, dilations, local_condition=None):
+    """wavenet_ops.py:117-138 -> (skip_connection, residual_connection).
+    params: gated/{kernel,bias}, gated/local_condition/kernel, skip/{kernel,bias}, residual/{kernel,bias}."""
+    gated = gated_cnn(net, params['gated/kernel'], params['gated/bias'], dilations, local_condition,
+                      params.get('gated/local_condition/kernel'))
+    skip = conv1d_v2(gated, params['skip/kernel'], params['skip/bias'])
+    res = conv1d_v2(gated, params['residual/kernel'], params['residual/bias'])
+    return skip, res
+
+
+def _keras_conv1d(net, kernel, bias, stride, relu):
+    B, T, Cin = net.shape
+    k, _, Cout = kernel.shape
+    To = -(-T // stride)
+    total = max((To - 1) * stride + k - T, 0)       # TF 'SAME' 
+    y = torch.empty(B, Cout, To, device=net.device)
+    x = _bct(net)
+    L.check(L.lib().vqw_conv1d_same_fwd(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), B, Cin, Cout, T,
+                                        To, k, stride, total // 2, int(relu), L.stream()))
+    return _btc(y)
+
+
+def conv_3_768(net, kernel, bias, relu='relu'):
+    """encoder_ops.py:46-52 (Keras Conv1D k=3, 'same', relu)."""
+    return _keras_conv1d(net, kernel, bias, 1, relu == 'relu')
+
+
+def strided_conv_4_768(net, kernel, bias, relu='relu'):
+    """encoder_ops.py:55-61 (k=4, stride 2, 'same')."""
+    return _keras_conv1d(net, kernel, bias, 2, relu == 'relu')
+
+
+def linear_64(net, kernel, bias):
+    """encoder_ops.py:64-70 (1x1, no activation)."""
+    return _keras_conv1d(net, kernel, bias, 1, False)
+
+
+def concat(net, global_condition):
+    """decoder_ops.py:39-43."""
+    return torch.cat([net, global_condition.expand(-1, net.shape[1], -1)], dim=-1)
