@@ -67,18 +67,23 @@ __device__ __forceinline__ float mu_dec(float idx) {
 // wavenet.py:113-124: x = mu_law_encode(input_t); fast_conv1d(k=pre_k, dilation 1, Cin=1).
 __global__ void ar_pre_kernel(const ArState* st, const float* prev, float* xring, const float* pre_w,
                               const float* pre_b, float* cur, int pre_k, int R) {
+    __shared__ float taps[64];
     const int b = blockIdx.x;
     const int step = st->step;
     float* ring = xring + (size_t)b * pre_k;
-    if (threadIdx.x == 0) ring[step % pre_k] = mu_enc(prev[b]);
+    const float x_new = mu_enc(prev[b]);
+    if (threadIdx.x < pre_k) {
+        const int j = threadIdx.x;                      // tap j multiplies x(t - (pre_k-1-j))
+        const int tau = step - (pre_k - 1 - j);
+        const int slot = ((tau % pre_k) + pre_k) % pre_k;
+        taps[j] = (j == pre_k - 1) ? x_new : ring[slot];
+        if (j == pre_k - 1) ring[slot] = x_new;         // push (the slot of t - pre_k, no longer needed)
+    }
     __syncthreads();
     for (int o = threadIdx.x; o < R; o += blockDim.x) {
         float acc = pre_b[o];
-        for (int j = 0; j < pre_k; ++j) {
-            const int tau = step - (pre_k - 1 - j);
-            const int slot = ((tau % pre_k) + pre_k) % pre_k;
-            acc = fmaf(pre_w[(size_t)j * R + o], ring[slot], acc);
-        }
+#pragma unroll 8
+        for (int j = 0; j < pre_k; ++j) acc = fmaf(pre_w[(size_t)j * R + o], taps[j], acc);
         cur[(size_t)b * R + o] = acc;
     }
 }
@@ -107,29 +112,52 @@ __global__ __launch_bounds__(256) void ar_gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[b][e] = 0.0f;
 
-    float* xs = sm;  // [B][Kmax] staged input vector
-    for (int sgi = 0; sgi < a.nseg; ++sgi) {
-        const GemvSeg& sg = a.seg[sgi];
-        const float* xp = sg.x;
-        if (sg.depth > 0) xp += (size_t)((step + sg.phase) % sg.depth) * B * sg.K;
-        __syncthreads();
-        for (int i = tid; i < B * sg.K; i += 256) {
-            const float v = xp[i];
-            xs[i] = a.in_relu ? fmaxf(v, 0.0f) : v;
+    // The per-sample chain is latency-bound: stage the input vectors of ALL segments behind one
+    // barrier, then issue every weight load of a segment before the first one is consumed
+    // (K <= 256 per segment in the default model: 4 loads in flight per thread and segment).
+    float* xs = sm;  // [seg][B][K]
+    {
+        int off = 0;
+        for (int sgi = 0; sgi < a.nseg; ++sgi) {
+            const GemvSeg& sg = a.seg[sgi];
+            const float* xp = sg.x;
+            if (sg.depth > 0) xp += (size_t)((step + sg.phase) % sg.depth) * B * sg.K;
+            for (int i = tid; i < B * sg.K; i += 256) {
+                const float v = xp[i];
+                xs[off + i] = a.in_relu ? fmaxf(v, 0.0f) : v;
+            }
+            off += B * sg.K;
         }
-        __syncthreads();
-        if (colok) {
-            for (int k = kl; k < sg.K; k += 64) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(sg.w + (size_t)k * sg.ldw + col);
+    }
+    __syncthreads();
+    if (colok) {
+        int off = 0;
+        for (int sgi = 0; sgi < a.nseg; ++sgi) {
+            const GemvSeg& sg = a.seg[sgi];
+            const float* wc = sg.w + col;
+            for (int k0 = 0; k0 < sg.K; k0 += 256) {
+                f32x4 w4[4];
+                int kc[4];
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b) {
-                    if (b < B) {
-                        const float xv = xs[b * sg.K + k];
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k0 + kl + 64 * u;
+                    kc[u] = min(kk, sg.K - 1);
+                    w4[u] = *reinterpret_cast<const f32x4*>(wc + (size_t)kc[u] * sg.ldw);
+                    if (kk >= sg.K) w4[u] = f32x4{0, 0, 0, 0};
+                }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[b][e] = fmaf(w4[e], xv, acc[b][e]);
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) {
+                        if (b < B) {
+                            const float xv = xs[off + b * sg.K + kc[u]];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[b][e] = fmaf(w4[u][e], xv, acc[b][e]);
+                        }
                     }
                 }
             }
+            off += B * sg.K;
         }
     }
     // reduce over the 64 k-lanes: lanes of one wave hold kl = 16w..16w+15 (4 lanes each)
@@ -329,7 +357,7 @@ int launch_step(vqw_ar_decoder* h, hipStream_t st) {
         }
         a.nseg = ks; a.B = B; a.N = 2 * R; a.H = R; a.bias = h->gated_b[l];
         a.cond = h->condenc[l]; a.out = h->gated; a.st = h->st;
-        hipLaunchKernelGGL((ar_gemv_kernel<MODE_GATE>), dim3(vqw_cdiv(R, 8)), dim3(256), B * R * sizeof(float) + 4 * MAXB * 16 * sizeof(float), st, a);
+        hipLaunchKernelGGL((ar_gemv_kernel<MODE_GATE>), dim3(vqw_cdiv(R, 8)), dim3(256), (size_t)ks * B * R * sizeof(float) + 4 * MAXB * 16 * sizeof(float), st, a);
         // skip / residual linears + accumulation + queue push (wavenet_ops.py:261-265, wavenet.py:142-143)
         memset(&a, 0, sizeof(a));
         a.seg[0] = GemvSeg{h->out_w[l], h->gated, R, w.out_ld, 0, 0};
@@ -374,7 +402,7 @@ extern "C" int vqw_ar_decode_create(vqw_ar_decoder** out, const vqw_ar_weights* 
     VQW_CHECK(batch >= 1 && batch <= MAXB, "vqw_ar_decode_create: batch=%d must be in 1..%d", batch, MAXB);
     VQW_CHECK(w->n_layers >= 1 && w->kernel_size >= 2 && w->kernel_size <= VQW_MAX_TAPS, "vqw_ar_decode_create: bad layer config");
     VQW_CHECK(w->R % 16 == 0 && w->S % 16 == 0 && w->Q % 4 == 0 && w->Cc % 16 == 0, "vqw_ar_decode_create: R,S,Cc must be multiples of 16, Q of 4");
-    VQW_CHECK(w->Q <= 1024, "vqw_ar_decode_create: Q must be <= 1024");
+    VQW_CHECK(w->Q <= 1024 && w->pre_k <= 64, "vqw_ar_decode_create: Q must be <= 1024 and pre_k <= 64");
     VQW_CHECK(w->pre_k >= 1 && w->dilations && w->gated_w && w->gated_b && w->cond_w && w->out_w && w->out_b, "vqw_ar_decode_create: null weight table");
     vqw_ar_decoder* h = new vqw_ar_decoder();
     h->w = *w;
