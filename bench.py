@@ -137,6 +137,7 @@ def main():
     ap.add_argument('--gen-steps', type=int, default=1024, help='AR samples to generate for the generation rate')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 code path)")
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -144,13 +145,17 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus and world > 1:
         raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, a.gpus))
+    local = local % max(torch.cuda.device_count(), 1)   # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module('vq-vae-wavenet_amd')
     K = pkg.kernels
