@@ -74,8 +74,19 @@ def init_params(mcfg, wcfg, num_speakers, seed=0, randomize_all=False):
         return torch.full((n,), float(base))
 
     P['speaker_embedding'] = _uus(rng, (num_speakers, Cs), 2.0)          # model.py:23-26
+    if mcfg.get("encoder", "64") == "Magenta":                           # encoder.py:38-63
+        Fm = 128
+        P['encoder/preprocess/kernel'] = _uus(rng, (5, 1, Fm), 1.0)
+        P['encoder/preprocess/bias'] = small(Fm)
+        for i in range(6):
+            s = 'encoder/cycle_1/layer_%d' % (i + 1)
+            for scope, k in (('dilated', 1), ('gate', 5), ('filter', 5), ('residual', 1)):
+                P['%s/%s/kernel' % (s, scope)] = _uus(rng, (k, Fm, Fm), 1.0)
+                P['%s/%s/bias' % (s, scope)] = small(Fm)
+        P['encoder/postprocess/kernel'] = _uus(rng, (1, Fm, D), 1.0)
+        P['encoder/postprocess/bias'] = small(D)
     cin = 1
-    for i in range(6):                                                    # encoder.py:14-20
+    for i in range(6 if mcfg.get("encoder", "64") == "64" else 0):       # encoder.py:14-20
         P[conv_scope(i) + '/kernel'] = _glorot(rng, (5, cin, F_enc))
         P[conv_scope(i) + '/bias'] = small(F_enc)
         P[bn_scope(i) + '/gamma'] = small(F_enc, 1.0)
@@ -83,12 +94,13 @@ def init_params(mcfg, wcfg, num_speakers, seed=0, randomize_all=False):
         P[bn_scope(i) + '/moving_mean'] = torch.zeros(F_enc)
         P[bn_scope(i) + '/moving_variance'] = torch.ones(F_enc)
         cin = F_enc
-    P[conv_scope(6) + '/kernel'] = _glorot(rng, (1, F_enc, D))            # encoder.py:21-25
-    P[conv_scope(6) + '/bias'] = small(D)
-    P[bn_scope(6) + '/gamma'] = small(D, 1.0)
-    P[bn_scope(6) + '/beta'] = small(D)
-    P[bn_scope(6) + '/moving_mean'] = torch.zeros(D)
-    P[bn_scope(6) + '/moving_variance'] = torch.ones(D)
+    if mcfg.get("encoder", "64") == "64":
+        P[conv_scope(6) + '/kernel'] = _glorot(rng, (1, F_enc, D))        # encoder.py:21-25
+        P[conv_scope(6) + '/bias'] = small(D)
+        P[bn_scope(6) + '/gamma'] = small(D, 1.0)
+        P[bn_scope(6) + '/beta'] = small(D)
+        P[bn_scope(6) + '/moving_mean'] = torch.zeros(D)
+        P[bn_scope(6) + '/moving_variance'] = torch.ones(D)
     P['embedding/embedding'] = _uus(rng, (mcfg["k"], D), 1.7)            # model.py:47-49
 
     Cc = D + Cs                                                          # decoder_ops.py:39-43
@@ -137,6 +149,21 @@ def encoder_64(x, P):
     b = bn_scope(6)
     return R.batch_norm_inference(net, P[b + '/gamma'], P[b + '/beta'],
                                   P[b + '/moving_mean'], P[b + '/moving_variance'])
+
+
+def encoder_magenta(x, P):
+    """encoder.py:38-63 (Encoder_Magenta).  x [B,T,1] -> [B,T/64,D].  NB: tanh is applied to the
+    'gate' scope's output and sigmoid to the 'filter' scope's (encoder.py:59)."""
+    net = R.mu_law_encode(R.shift_right(x))
+    en = R.conv1d_v2(net, P['encoder/preprocess/kernel'], P['encoder/preprocess/bias'])
+    for i, d in enumerate([1, 2, 4, 8, 16, 16]):
+        s = 'encoder/cycle_1/layer_%d' % (i + 1)
+        dd = R.conv1d_v2(en, P[s + '/dilated/kernel'], P[s + '/dilated/bias'], 1, stride=2)
+        g = R.conv1d_v2(dd, P[s + '/gate/kernel'], P[s + '/gate/bias'], d)
+        f = R.conv1d_v2(dd, P[s + '/filter/kernel'], P[s + '/filter/bias'], d)
+        gated = torch.tanh(g) * torch.sigmoid(f)
+        en = dd + R.conv1d_v2(gated, P[s + '/residual/kernel'], P[s + '/residual/bias'])
+    return R.conv1d_v2(en, P['encoder/postprocess/kernel'], P['encoder/postprocess/bias'])
 
 
 def vq_distances_np(z, emb):
@@ -192,7 +219,7 @@ def wavenet_build(x, local_condition, P, wcfg, collect=None):
 
 def forward(x, speaker_idx, P, mcfg, wcfg, collect=None):
     """model.py:145-151 (build) up to the losses.  x [B,T,1], speaker_idx int64 [B]."""
-    z_e = encoder_64(x, P)                                               # model.py:36
+    z_e = (encoder_magenta if mcfg.get("encoder", "64") == "Magenta" else encoder_64)(x, P)   # model.py:36
     if mcfg["use_vq"]:
         q, e_k, z_q = discretise(z_e, P['embedding/embedding'])         # model.py:57-74
     else:

@@ -187,3 +187,11 @@ def test_fast_generation_matches_oracle(pkg):
     gen.close()
     with pytest.raises(NotImplementedError):
         pkg.generator.FastGenerator(model, batch=1).generate(enc[:1].contiguous(), 4, mode='beam')
+
+
+def test_magenta_encoder_model_parity(pkg):
+    """Encoder_Magenta (encoder.py:29-63) wired into the same VQ + decoder: two full train steps."""
+    m, w = tiny_cfg()
+    m = dict(m, encoder='Magenta')
+    worst = run_parity(pkg, m, w, 10, 2, 512, seed=21, steps=2)
+    print('worst grad', worst)

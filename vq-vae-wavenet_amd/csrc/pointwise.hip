@@ -74,81 +74,100 @@ __global__ void wavenet_inputs_kernel(const float* __restrict__ x, float* __rest
 
 // ----------------------------------------------------------------------------- Cin == 1 convs
 // wavenet.py:42-44 (preprocess, causal k=32) and encoder.py:15 layer 1 (k=5, stride 2, SAME).
-template <int KMAX>
-__global__ void conv_cin1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                     const float* __restrict__ bias, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, float* __restrict__ out,
-                                     float* __restrict__ save_r, int T_in, int T_out, int F, int k,
-                                     int stride, int offset, int relu) {
-    const int f = blockIdx.y, b = blockIdx.z;
-    const int t0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (t0 >= T_out) return;
+// Block = 256 threads x 4 consecutive output times for FT output channels; the input window of
+// the block (stride*1024 + k samples) is staged once in LDS and the taps of the block's channels
+// sit in LDS too, so the kernel is bound by its output stream (HBM), not by scalar loads.
+template <int KMAX, int FT>
+__global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+    float* __restrict__ save_r, int T_in, int T_out, int F, int k, int stride, int offset, int relu) {
+    extern __shared__ float cs[];
+    const int f0 = blockIdx.y * FT, b = blockIdx.z;
+    const int tb = 4 * blockIdx.x * 256;                  // first output time of the block
+    const int win = stride * 1024 + KMAX;                 // staged input samples
+    float* xs = cs;                                       // [win]
+    float* ws = cs + win;                                 // [KMAX][FT]
     const float* xr = x + (size_t)b * T_in;
-    float acc[4];
-    const float bv = bias ? bias[f] : 0.0f;
+    const int i0 = stride * tb + offset;                  // input index of xs[0]
+    for (int i = threadIdx.x; i < win; i += 256) {
+        const int ti = i0 + i;
+        xs[i] = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < KMAX * FT; i += 256) {
+        const int j = i / FT, ff = i % FT;
+        ws[i] = (j < k && f0 + ff < F) ? w[(size_t)j * F + f0 + ff] : 0.0f;
+    }
+    __syncthreads();
+    const int t0 = tb + 4 * threadIdx.x;
+    if (t0 >= T_out) return;
+    const int xo = stride * 4 * threadIdx.x;
+    for (int ff = 0; ff < FT; ++ff) {
+        const int f = f0 + ff;
+        if (f >= F) break;
+        float acc[4];
+        const float bv = bias ? bias[f] : 0.0f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = bv;
+        for (int e = 0; e < 4; ++e) acc[e] = bv;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-        if (j < k) {
-            const float wv = w[(size_t)j * F + f];
+        for (int j = 0; j < KMAX; ++j) {
+            const float wv = ws[j * FT + ff];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ti = stride * (t0 + e) + j + offset;
-                const float xv = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
-                acc[e] = fmaf(wv, xv, acc[e]);
-            }
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, xs[xo + stride * e + j], acc[e]);
         }
-    }
-    const size_t ro = ((size_t)b * F + f) * T_out;
-    float r[4], y[4];
+        const size_t ro = ((size_t)b * F + f) * T_out;
+        float r[4], y[4];
+        const float sc = scale ? scale[f] : 1.0f, sh = scale ? shift[f] : 0.0f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r[e] = relu ? fmaxf(acc[e], 0.0f) : acc[e];
-        y[e] = scale ? scale[f] * r[e] + shift[f] : r[e];
-    }
-    if (t0 + 3 < T_out && (T_out & 3) == 0) {
-        *reinterpret_cast<f32x4*>(out + ro + t0) = f32x4{y[0], y[1], y[2], y[3]};
-        if (save_r) *reinterpret_cast<f32x4*>(save_r + ro + t0) = f32x4{r[0], r[1], r[2], r[3]};
-    } else {
+        for (int e = 0; e < 4; ++e) {
+            r[e] = relu ? fmaxf(acc[e], 0.0f) : acc[e];
+            y[e] = scale ? sc * r[e] + sh : r[e];
+        }
+        if (t0 + 3 < T_out && (T_out & 3) == 0) {
+            *reinterpret_cast<f32x4*>(out + ro + t0) = f32x4{y[0], y[1], y[2], y[3]};
+            if (save_r) *reinterpret_cast<f32x4*>(save_r + ro + t0) = f32x4{r[0], r[1], r[2], r[3]};
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (t0 + e < T_out) {
-                out[ro + t0 + e] = y[e];
-                if (save_r) save_r[ro + t0 + e] = r[e];
-            }
+            for (int e = 0; e < 4; ++e)
+                if (t0 + e < T_out) {
+                    out[ro + t0 + e] = y[e];
+                    if (save_r) save_r[ro + t0 + e] = r[e];
+                }
+        }
     }
 }
 
+// dw[j][f] += sum_t x[stride*t+j+offset] * dout[f][t]: same staging; every thread keeps KMAX partial
+// sums for one channel at a time, reduced over the block with wavefront shuffles.
 template <int KMAX>
-__global__ void conv_cin1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                       float* __restrict__ dw, int T_in, int T_out, int F, int k,
-                                       int stride, int offset) {
+__global__ __launch_bounds__(256) void conv_cin1_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dw, int T_in,
+    int T_out, int F, int k, int stride, int offset) {
+    extern __shared__ float cs[];
     __shared__ float red[4][KMAX];
     const int f = blockIdx.y, b = blockIdx.z;
-    const int t0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int tb = 4 * blockIdx.x * 256;
+    const int win = stride * 1024 + KMAX;
+    float* xs = cs;
     const float* xr = x + (size_t)b * T_in;
-    const float* dr = dout + ((size_t)b * F + f) * T_out;
-    float acc[KMAX];
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) acc[j] = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int t = t0 + e;
-        const float dv = (t < T_out) ? dr[t] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j) {
-            if (j < k) {
-                const int ti = stride * t + j + offset;
-                const float xv = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
-                acc[j] = fmaf(xv, dv, acc[j]);
-            }
-        }
+    const int i0 = stride * tb + offset;
+    for (int i = threadIdx.x; i < win; i += 256) {
+        const int ti = i0 + i;
+        xs[i] = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
     }
+    __syncthreads();
+    const int t0 = tb + 4 * threadIdx.x;
+    const float* dr = dout + ((size_t)b * F + f) * T_out;
+    float dv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[e] = (t0 + e < T_out) ? dr[t0 + e] : 0.0f;
+    const int xo = stride * 4 * threadIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
-        float v = acc[j];
+        float v = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v = fmaf(xs[xo + stride * e + j], dv[e], v);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if (lane == 0) red[wid][j] = v;
@@ -363,11 +382,13 @@ extern "C" int vqw_conv_cin1_fwd(const float* x, const float* w, const float* bi
     VQW_CHECK(x && w && out, "vqw_conv_cin1_fwd: null pointer");
     VQW_CHECK(B > 0 && T_in > 0 && T_out > 0 && F > 0 && k >= 1 && k <= 32 && stride >= 1, "vqw_conv_cin1_fwd: bad shape (k<=32)");
     VQW_CHECK(!scale || shift, "vqw_conv_cin1_fwd: scale needs shift");
-    dim3 grid(vqw_cdiv(vqw_cdiv(T_out, 4), 256), F, B);
+    VQW_CHECK(stride <= 4, "vqw_conv_cin1_fwd: stride must be <= 4");
+    constexpr int FT = 16;
+    dim3 grid(vqw_cdiv(vqw_cdiv(T_out, 4), 256), vqw_cdiv(F, FT), B);
     if (k <= 8)
-        hipLaunchKernelGGL((conv_cin1_fwd_kernel<8>), grid, dim3(256), 0, (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
+        hipLaunchKernelGGL((conv_cin1_fwd_kernel<8, FT>), grid, dim3(256), (stride * 1024 + 8 + 8 * FT) * sizeof(float), (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
     else
-        hipLaunchKernelGGL((conv_cin1_fwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
+        hipLaunchKernelGGL((conv_cin1_fwd_kernel<32, FT>), grid, dim3(256), (stride * 1024 + 32 + 32 * FT) * sizeof(float), (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
     VQW_LAUNCH_CHECK("vqw_conv_cin1_fwd");
     return 0;
 }
@@ -376,11 +397,12 @@ extern "C" int vqw_conv_cin1_wgrad(const float* x, const float* dout, float* dw,
                                    int F, int k, int stride, int offset, vqw_stream_t s) {
     VQW_CHECK(x && dout && dw, "vqw_conv_cin1_wgrad: null pointer");
     VQW_CHECK(B > 0 && T_in > 0 && T_out > 0 && F > 0 && k >= 1 && k <= 32 && stride >= 1, "vqw_conv_cin1_wgrad: bad shape (k<=32)");
+    VQW_CHECK(stride <= 4, "vqw_conv_cin1_wgrad: stride must be <= 4");
     dim3 grid(vqw_cdiv(vqw_cdiv(T_out, 4), 256), F, B);
     if (k <= 8)
-        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<8>), grid, dim3(256), 0, (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
+        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<8>), grid, dim3(256), (stride * 1024 + 8) * sizeof(float), (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
     else
-        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<32>), grid, dim3(256), 0, (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
+        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<32>), grid, dim3(256), (stride * 1024 + 32) * sizeof(float), (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
     VQW_LAUNCH_CHECK("vqw_conv_cin1_wgrad");
     return 0;
 }

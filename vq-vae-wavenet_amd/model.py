@@ -17,6 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import kernels as K
+from .encoders import EncoderMagenta
 
 BN_EPS = 1e-3  # Keras BatchNormalization default epsilon
 
@@ -50,8 +51,9 @@ class VQVAE:
     """model.py:7-159.  encoder '64' + VQ + speaker embedding + WaveNet decoder."""
 
     def __init__(self, model_cfg, wavenet_cfg, num_speakers, device='cuda', seed=0):
-        if model_cfg.get('encoder', '64') != '64':
-            raise NotImplementedError('encoder %s not implemented' % model_cfg.get('encoder'))
+        self.enc = model_cfg.get('encoder', '64')
+        if self.enc not in ('64', 'Magenta'):     # '2019' (MFCC front end): not built yet (DESIGN.md 7)
+            raise NotImplementedError('encoder %s not implemented' % self.enc)
         self.m, self.w = model_cfg, wavenet_cfg
         self.dev = torch.device(device)
         self.S_spk = num_speakers
@@ -64,6 +66,7 @@ class VQVAE:
         if not self.use_vq or self.Cs <= 0:
             raise NotImplementedError('this build implements the default use_vq=true, speaker_embedding>0 path')
         self.Cc = self.D + self.Cs
+        self.magenta = EncoderMagenta(self.D) if self.enc == 'Magenta' else None
         w = wavenet_cfg
         self.dil = list(w['dilation_rates'])
         self.L = len(self.dil)
@@ -92,13 +95,16 @@ class VQVAE:
         F, D, R, S, Q, L, ks, Cc = self.F, self.D, self.R, self.S, self.Q, self.L, self.ks, self.Cc
         seg = OrderedDict()  # internal (grouped) tensors of the flat buffer
         seg['speaker_embedding'] = (self.S_spk, self.Cs)
-        seg['enc_w0'] = (5, F)                 # conv1d/kernel [5,1,F]
-        seg['enc_w'] = (5, 5, F, F)            # conv1d_1..5/kernel
-        seg['enc_b'] = (6, F)
-        seg['enc_w6'] = (F, D)                 # conv1d_6/kernel [1,F,D]
-        seg['enc_b6'] = (D,)
-        seg['bn_gamma'] = (6 * F + D,)
-        seg['bn_beta'] = (6 * F + D,)
+        if self.enc == '64':
+            seg['enc_w0'] = (5, F)                 # conv1d/kernel [5,1,F]
+            seg['enc_w'] = (5, 5, F, F)            # conv1d_1..5/kernel
+            seg['enc_b'] = (6, F)
+            seg['enc_w6'] = (F, D)                 # conv1d_6/kernel [1,F,D]
+            seg['enc_b6'] = (D,)
+            seg['bn_gamma'] = (6 * F + D,)
+            seg['bn_beta'] = (6 * F + D,)
+        else:
+            seg.update(self.magenta.segments())
         seg['embedding'] = (self.Kc, D)
         seg['pre_w'] = (self.pre_k, R)
         seg['pre_b'] = (R,)
@@ -147,10 +153,13 @@ class VQVAE:
         F, D, R, S, Q, L, ks, Cc = self.F, self.D, self.R, self.S, self.Q, self.L, self.ks, self.Cc
         P = self.P
         P['speaker_embedding'].copy_(uus((self.S_spk, self.Cs), self.S_spk, 2.0))   # model.py:23-26
-        P['enc_w0'].copy_(glorot((5, F), 5, 1, F))
-        P['enc_w'].copy_(glorot((5, 5, F, F), 5, F, F))
-        P['enc_w6'].copy_(glorot((F, D), 1, F, D))
-        P['bn_gamma'].fill_(1.0)
+        if self.enc == '64':
+            P['enc_w0'].copy_(glorot((5, F), 5, 1, F))
+            P['enc_w'].copy_(glorot((5, 5, F, F), 5, F, F))
+            P['enc_w6'].copy_(glorot((F, D), 1, F, D))
+            P['bn_gamma'].fill_(1.0)
+        else:
+            self.magenta.init(P, uus)
         P['embedding'].copy_(uus((self.Kc, D), self.Kc, 1.7))                       # model.py:47-49
         P['pre_w'].copy_(uus((self.pre_k, R), self.pre_k, 1.0))                     # wavenet_ops.py:69
         P['skip0_w'].copy_(uus((R, S), R, 1.0))
@@ -169,9 +178,12 @@ class VQVAE:
             'post2_w': torch.empty(Q, S, device=dev),
             'skip0_w': torch.empty(S, R, device=dev),
             'cond_w': torch.empty(self.Mall, Cc, device=dev),
-            'enc_w': torch.empty(5, 5, F, F, device=dev),
-            'enc_w6': torch.empty(D, F, device=dev),
         }
+        if self.enc == '64':
+            self.T['enc_w'] = torch.empty(5, 5, F, F, device=dev)
+            self.T['enc_w6'] = torch.empty(D, F, device=dev)
+        else:
+            self.T.update(self.magenta.scratch(dev))
 
     # ------------------------------------------------------------------ reference-name views
     def _named(self, V, bn_stats=True):
@@ -179,21 +191,24 @@ class VQVAE:
         F, D, R, S, L = self.F, self.D, self.R, self.S, self.L
         out = OrderedDict()
         out['speaker_embedding'] = V['speaker_embedding']
-        out['encoder/conv1d/kernel'] = V['enc_w0'].reshape(5, 1, F)
-        for i in range(1, 6):
-            out['encoder/conv1d_%d/kernel' % i] = V['enc_w'][i - 1]
-        for i in range(6):
-            out['encoder/conv1d%s/bias' % _suffix(i)] = V['enc_b'][i]
-        out['encoder/conv1d_6/kernel'] = V['enc_w6'].reshape(1, F, D)
-        out['encoder/conv1d_6/bias'] = V['enc_b6']
-        for i in range(7):
-            n = F if i < 6 else D
-            sl = slice(i * F, i * F + n)
-            out['encoder/batch_normalization%s/gamma' % _suffix(i)] = V['bn_gamma'][sl]
-            out['encoder/batch_normalization%s/beta' % _suffix(i)] = V['bn_beta'][sl]
-            if bn_stats:
-                out['encoder/batch_normalization%s/moving_mean' % _suffix(i)] = self.bn_mean[sl]
-                out['encoder/batch_normalization%s/moving_variance' % _suffix(i)] = self.bn_var[sl]
+        if self.enc == '64':
+            out['encoder/conv1d/kernel'] = V['enc_w0'].reshape(5, 1, F)
+            for i in range(1, 6):
+                out['encoder/conv1d_%d/kernel' % i] = V['enc_w'][i - 1]
+            for i in range(6):
+                out['encoder/conv1d%s/bias' % _suffix(i)] = V['enc_b'][i]
+            out['encoder/conv1d_6/kernel'] = V['enc_w6'].reshape(1, F, D)
+            out['encoder/conv1d_6/bias'] = V['enc_b6']
+            for i in range(7):
+                n = F if i < 6 else D
+                sl = slice(i * F, i * F + n)
+                out['encoder/batch_normalization%s/gamma' % _suffix(i)] = V['bn_gamma'][sl]
+                out['encoder/batch_normalization%s/beta' % _suffix(i)] = V['bn_beta'][sl]
+                if bn_stats:
+                    out['encoder/batch_normalization%s/moving_mean' % _suffix(i)] = self.bn_mean[sl]
+                    out['encoder/batch_normalization%s/moving_variance' % _suffix(i)] = self.bn_var[sl]
+        else:
+            self.magenta.named(V, out)
         out['embedding/embedding'] = V['embedding']
         out['decoder/preprocess/kernel'] = V['pre_w'].reshape(self.pre_k, 1, R)
         out['decoder/preprocess/bias'] = V['pre_b']
@@ -252,9 +267,13 @@ class VQVAE:
         ws['Tl'] = [T // (2 ** (i + 1)) for i in range(6)]
         ws['inputs'] = e(B, T)
         ws['labels'] = torch.empty(B, T, dtype=torch.int32, device=dev)
-        ws['X'] = [e(B, F, t) for t in ws['Tl']]      # BN outputs of encoder layers 0..5
-        ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
-        ws['y6'] = e(B, D, Tz)
+        if self.enc == '64':
+            ws['X'] = [e(B, F, t) for t in ws['Tl']]      # BN outputs of encoder layers 0..5
+            ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
+            ws['y6'] = e(B, D, Tz)
+            ws['dX'] = [e(B, F, t) for t in ws['Tl']]
+        else:
+            self.magenta.workspace(ws, B, T, dev)
         ws['z_e'] = e(B, D, Tz)
         ws['idx'] = torch.empty(B, Tz, dtype=torch.int64, device=dev)
         ws['e_k'] = e(B, D, Tz)
@@ -274,7 +293,6 @@ class VQVAE:
         ws['dcondenc'] = e(B, self.Mall, Tz)
         ws['dcond'] = e(B, self.Cc, Tz)
         ws['dz'] = e(B, D, Tz)
-        ws['dX'] = [e(B, F, t) for t in ws['Tl']]
         ws['bskip'] = e(S)
         ws['scale'] = e(6 * F + D)
         ws['shift'] = e(6 * F + D)
@@ -293,6 +311,10 @@ class VQVAE:
     def _encode(self, x, spk, ws, save=True):
         """encoder.py:13-26 + model.py:57-74 + decoder_ops.py:39-43 -> ws['cond'] [B][Cc][Tz]."""
         P, F, D, B, T = self.P, self.F, self.D, ws['B'], ws['T']
+        if self.enc != '64':
+            self.magenta.forward(x, ws, P, save)
+            self._quantise(spk, ws)
+            return
         self._bn_affine(ws)
         sc, sh = ws['scale'], ws['shift']
         pl, _ = same_pads(T, 5, 2)
@@ -310,6 +332,11 @@ class VQVAE:
         Tz = ws['Tz']
         K.conv_gemm(x0=ws['X'][5], w=P['enc_w6'], bias=P['enc_b6'], out0=ws['z_e'], save0=ws['y6'] if save else None,
                     scale=sc[6 * F:], shift=sh[6 * F:], B=B, T_in=Tz, T_out=Tz, M=D, C0=F, taps=[0])
+        self._quantise(spk, ws)
+
+    def _quantise(self, spk, ws):
+        """model.py:57-74 (VQ) + model.py:22-27 / decoder_ops.py:39-43 (speaker embedding tiled over time)."""
+        P, D, Tz = self.P, self.D, ws['Tz']
         K.vq_nearest_fwd(ws['z_e'], P['embedding'], idx=ws['idx'], e_k=ws['e_k'], zq=ws['cond'],
                          zq_bstride=self.Cc * Tz, mind=ws['mind'])
         K.speaker_tile_fwd(P['speaker_embedding'], spk, ws['cond'], cond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs, Tz=Tz)
@@ -374,8 +401,11 @@ class VQVAE:
         K.transpose(P['post2_w'], Tt['post2_w'], 1, S, self.Q)
         K.transpose(P['skip0_w'], Tt['skip0_w'], 1, R, S)
         K.transpose(P['cond_w'], Tt['cond_w'], 1, self.Cc, self.Mall)
-        K.transpose(P['enc_w'], Tt['enc_w'], 25, F, F)
-        K.transpose(P['enc_w6'], Tt['enc_w6'], 1, F, self.D)
+        if self.enc == '64':
+            K.transpose(P['enc_w'], Tt['enc_w'], 25, F, F)
+            K.transpose(P['enc_w6'], Tt['enc_w6'], 1, F, self.D)
+        else:
+            self.magenta.transpose(P, Tt)
 
     def backward(self, x, spk, ws):
         """Gradients of loss = CE + vq + commitment (model.py:90-106) w.r.t. every trainable
@@ -445,6 +475,11 @@ class VQVAE:
         nd = float(B * Tz * D)
         K.vq_nearest_bwd(ws['z_e'], ws['e_k'], ws['idx'], dzq=ws['dcond'], dzq_bstride=self.Cc * Tz, dz_e=ws['dz'],
                          demb=G['embedding'], cscale=2.0 * self.beta / nd, escale=2.0 / nd, K=self.Kc)
+        if self.enc != '64':
+            self.magenta.backward(x, ws, P, G, Tt)
+            if self.grad_sync is not None:
+                self.grad_sync.bucket_ready(0, self.seg_off['pre_w'][0])
+            return
         # ---- encoder (encoder.py:13-26), BN in inference mode
         sc, dsc = ws['scale'], ws['dscale']
         dsc.zero_()
