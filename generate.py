@@ -90,7 +90,7 @@ def main():
         for b0 in range(0, B, 8):              # the AR decoder handles up to 8 rows at a time
             rows = slice(b0, min(b0 + 8, B))
             gen = pkg.generator.FastGenerator(model, batch=rows.stop - rows.start)
-            audio, _ = gen.generate(enc[rows].contiguous(), length, mode=args.mode,
+            audio, _ = gen.generate(enc[rows].contiguous(), length, mode=args.mode, ratio=length // enc.shape[2],
                                     uniforms=None if uniforms is None else uniforms[rows].contiguous())
             out[rows] = audio.cpu().numpy()
             gen.close()

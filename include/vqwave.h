@@ -61,7 +61,7 @@ int vqw_wavenet_inputs(const float* x, float* inputs, int32_t* labels, int B, in
  * ---------------------------------------------------------------------------------- */
 enum {
     VQW_EPI_STORE = 0,       /* v=acc+bias+cond; r=out_relu?max(v,0):v; save0=r;
-                                out=scale?scale*r+shift:r                                */
+                                out=(scale?scale*r+shift:r) + (aux1?aux1:0)              */
     VQW_EPI_ACCUM_SPLIT = 1, /* v=acc+bias; rows<M0: out0+=v; rows>=M0: out1=aux1+v      */
     VQW_EPI_GATE = 2,        /* M=2H rows (f,g pairs); out0=tanh(vf)*sigmoid(vg) [H rows];
                                 save0=tanh, save1=sigmoid                                */
@@ -170,6 +170,14 @@ int vqw_rowsum(const float* x, const float* y, float* seg_out, float* total, flo
  *   dz[b][c][t] = dx[b][c][t] * scale[c] * (r ? (r[b][c][t] > 0) : 1);  dz may alias dx.    */
 int vqw_bn_relu_bwd(const float* dx, const float* r, const float* scale, float* dz, int B,
                     int C, int T, vqw_stream_t s);
+
+/* MFCC front end of Encoder_2019 (encoder_ops.py:14-43): STFT (frame 400, step 160, periodic hann,
+ * zero pad at the end: frames = ceil(T/160)) -> magnitude (201 bins) -> mel [201][n_mel] (device
+ * matrix, tf linear_to_mel_weight_matrix) -> log(. + 1e-6) -> DCT-II * 2 / sqrt(2 n_mel) -> first n_keep
+ * coefficients.  x [B][T] -> out [B][C_out][frames], channels >= n_keep are written as zero (padding
+ * to the conv engine's multiple-of-16 channel count). */
+int vqw_mfcc(const float* x, const float* mel, float* out, int B, int T, int frames, int n_mel,
+             int n_keep, int C_out, vqw_stream_t s);
 
 /* dst[b][c][r] = src[b][r][c]  (batched 2-D transpose; per-tap kernel transposes) */
 int vqw_transpose(const float* src, float* dst, int batch, int rows, int cols,

@@ -85,6 +85,11 @@ def init_params(mcfg, wcfg, num_speakers, seed=0, randomize_all=False):
                 P['%s/%s/bias' % (s, scope)] = small(Fm)
         P['encoder/postprocess/kernel'] = _uus(rng, (1, Fm, D), 1.0)
         P['encoder/postprocess/bias'] = small(D)
+    if mcfg.get("encoder", "64") == "2019":                              # encoder.py:72-98
+        shapes = [(3, 13, 768), (3, 768, 768), (4, 768, 768)] + [(3, 768, 768)] * 6 + [(1, 768, D)]
+        for i, shp in enumerate(shapes):
+            P[conv_scope(i) + '/kernel'] = _glorot(rng, shp)
+            P[conv_scope(i) + '/bias'] = small(shp[2])
     cin = 1
     for i in range(6 if mcfg.get("encoder", "64") == "64" else 0):       # encoder.py:14-20
         P[conv_scope(i) + '/kernel'] = _glorot(rng, (5, cin, F_enc))
@@ -166,6 +171,21 @@ def encoder_magenta(x, P):
     return R.conv1d_v2(en, P['encoder/postprocess/kernel'], P['encoder/postprocess/bias'])
 
 
+def encoder_2019(x, P):
+    """encoder.py:72-98 (Encoder_2019) + encoder_ops.py:14-70.  x [B,T,1] -> [B,ceil(ceil(T/160)/2),D]."""
+    c = lambda i, net, **kw: R.keras_conv1d(net, P[conv_scope(i) + '/kernel'], P[conv_scope(i) + '/bias'], **kw)  # noqa: E731
+    net = R.mfcc(x[:, :, 0])
+    net = c(0, net, relu=True)
+    net = c(1, net, relu=True) + net
+    net = c(2, net, stride=2, relu=True)
+    for i in (3, 4):
+        net = c(i, net, relu=True) + net
+    for i in (5, 6, 7, 8):
+        relu = c(i, net, relu=True)
+        net = relu + relu                          # encoder.py:91-93: doubles, no residual
+    return c(9, net, relu=False)
+
+
 def vq_distances_np(z, emb):
     """model.py:60-61 direct form.  Summation order FIXED by this build (the TF order is
     unknown): d = 0..D-1 sequentially, each (z-e)*(z-e) and each add rounded to fp32."""
@@ -219,7 +239,7 @@ def wavenet_build(x, local_condition, P, wcfg, collect=None):
 
 def forward(x, speaker_idx, P, mcfg, wcfg, collect=None):
     """model.py:145-151 (build) up to the losses.  x [B,T,1], speaker_idx int64 [B]."""
-    z_e = (encoder_magenta if mcfg.get("encoder", "64") == "Magenta" else encoder_64)(x, P)   # model.py:36
+    z_e = {"Magenta": encoder_magenta, "2019": encoder_2019, "64": encoder_64}[mcfg.get("encoder", "64")](x, P)  # model.py:36
     if mcfg["use_vq"]:
         q, e_k, z_q = discretise(z_e, P['embedding/embedding'])         # model.py:57-74
     else:

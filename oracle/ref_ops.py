@@ -164,6 +164,42 @@ def batch_norm_inference(net, gamma, beta, mean, var, eps=1e-3):
     return gamma * (net - mean) / torch.sqrt(var + eps) + beta
 
 
+# ----------------------------------------------------------------------------
+# MFCC front end of Encoder_2019 (encoder_ops.py:14-43), restating the tf.contrib.signal ops
+# ----------------------------------------------------------------------------
+def linear_to_mel_weight_matrix(num_mel_bins=80, num_spectrogram_bins=201, sample_rate=16000,
+                                lower_edge_hertz=20.0, upper_edge_hertz=8000.0):
+    """tf.contrib.signal.linear_to_mel_weight_matrix (HTK mel scale, DC bin zeroed)."""
+    def hz_to_mel(f):
+        return 1127.0 * np.log1p(np.asarray(f, dtype=np.float64) / 700.0)
+    nyquist = sample_rate / 2.0
+    linear = np.linspace(0.0, nyquist, num_spectrogram_bins)[1:]
+    spec_mel = hz_to_mel(linear)[:, None]
+    edges = np.linspace(hz_to_mel(lower_edge_hertz), hz_to_mel(upper_edge_hertz), num_mel_bins + 2)
+    lower, center, upper = edges[:-2][None], edges[1:-1][None], edges[2:][None]
+    w = np.maximum(0.0, np.minimum((spec_mel - lower) / (center - lower), (upper - spec_mel) / (upper - center)))
+    return np.pad(w, [[1, 0], [0, 0]]).astype(np.float32)
+
+
+def mfcc(batch_wav):
+    """encoder_ops.py:14-43: batch_wav [B,T] -> [B, ceil(T/160), 13]."""
+    frame_length, frame_step, num_mel = 400, 160, 80
+    B, T = batch_wav.shape
+    frames = -(-T // frame_step)
+    pad = (frames - 1) * frame_step + frame_length - T                  # stft(pad_end=True)
+    xp = F.pad(batch_wav, (0, max(pad, 0)))
+    fr = xp.unfold(1, frame_length, frame_step)[:, :frames]              # [B,frames,400]
+    n = torch.arange(frame_length, dtype=torch.float32)
+    window = 0.5 - 0.5 * torch.cos(2 * math.pi * n / frame_length)      # hann_window(periodic=True)
+    stft = torch.abs(torch.fft.rfft(fr * window, n=frame_length))        # [B,frames,201]
+    feature = stft @ torch.from_numpy(linear_to_mel_weight_matrix(num_mel, stft.shape[-1]))
+    feature = torch.log(feature + 1e-6)
+    k = torch.arange(num_mel, dtype=torch.float32)
+    basis = torch.cos(math.pi * k[None, :] * (2 * torch.arange(num_mel, dtype=torch.float32)[:, None] + 1) / (2 * num_mel))
+    dct2 = 2.0 * (feature @ basis)                                       # tf.signal.dct(type=2)
+    return (dct2 * (1.0 / math.sqrt(2.0 * num_mel)))[..., :13]           # mfccs_from_log_mel_spectrograms
+
+
 def concat(net, global_condition):
     """decoder_ops.py:39-43."""
     g = global_condition.expand(-1, net.shape[1], -1)

@@ -48,7 +48,7 @@ def test_load_named_roundtrip_and_ema(pkg):
         model.load_named({'speaker_embedding': P['speaker_embedding']})
     assert model.lr_at(0) == 8e-5 and model.lr_at(80000) == 6e-5 and model.lr_at(10 ** 7) == 8e-6
     with pytest.raises(NotImplementedError):
-        pkg.model.VQVAE(dict(m, encoder='2019'), w, 7, device='cpu')
+        pkg.model.VQVAE(dict(m, encoder='1984'), w, 7, device='cpu')
     with pytest.raises(ValueError):
         model._workspace(2, 100)       # length must be a multiple of 64 (Encoder_64)
 

@@ -195,3 +195,29 @@ def test_magenta_encoder_model_parity(pkg):
     m = dict(m, encoder='Magenta')
     worst = run_parity(pkg, m, w, 10, 2, 512, seed=21, steps=2)
     print('worst grad', worst)
+
+
+def test_encoder_2019_model_parity(pkg):
+    """Encoder_2019 (encoder.py:66-98): MFCC-13 front end + 768-wide conv stack, T % 320 == 0,
+    one latent per 320 samples (so the decoder's condition ratio is 320, not 64)."""
+    m, w = tiny_cfg()
+    m = dict(m, encoder='2019')
+    worst = run_parity(pkg, m, w, 10, 2, 1280, seed=23, steps=2, grad_tol=3e-3, check_params=False)  # Adam: kernel test
+    print('worst grad', worst)
+
+
+def test_mfcc_kernel_matches_oracle(pkg):
+    from oracle import ref_ops as R
+    K = pkg.kernels
+    x, _, _ = M.synthetic_batch(3, 6400 + 160 * 3 + 57, 10, 5)      # ragged tail: zero padded frame
+    xb = x[:, :, 0].contiguous().cuda()
+    T = xb.shape[1]
+    frames = -(-T // 160)
+    out = torch.full((3, 16, frames), float('nan'), device='cuda')
+    mel = pkg.encoders.mel_weight_matrix().cuda()
+    assert torch.equal(mel.cpu(), torch.from_numpy(R.linear_to_mel_weight_matrix()))
+    K.mfcc(xb, mel, out)
+    want = R.mfcc(x[:, :, 0])                                        # [B,frames,13]
+    got = out[:, :13].permute(0, 2, 1).cpu()
+    assert float((got - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max()))
+    assert float(out[:, 13:].abs().max()) == 0.0

@@ -432,6 +432,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
 #pragma unroll
                         for (int f = 0; f < NT; ++f) v[f] = sc * v[f] + sh;
                     }
+                    if (d.aux1) {   // residual added after the activation: net = act(conv) + net
+                        float res[NT];
+                        load_row<NT>(d.aux1 + ((size_t)b * d.M + row) * Ts, tb, d.T_out, tstr, toff, vok, res);
+#pragma unroll
+                        for (int f = 0; f < NT; ++f) v[f] += res[f];
+                    }
                     float* dst = (row < d.M0)
                                      ? d.out0 + ((size_t)b * d.M0 + row) * Ts
                                      : d.out1 + ((size_t)b * (d.M - d.M0) + (row - d.M0)) * Ts;

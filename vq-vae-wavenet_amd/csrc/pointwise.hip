@@ -217,6 +217,77 @@ __global__ void rowsum_kernel(const float* __restrict__ x, const float* __restri
     }
 }
 
+// general (any T, any segment length) variant: one wave per row, segments one after another
+__global__ void rowsum_general_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                      float* __restrict__ seg_out, float* __restrict__ total, float alpha,
+                                      int rows, int C, int T, int seg) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * T;
+    const float* yr = y ? y + (size_t)row * T : nullptr;
+    const int sl = seg > 0 ? seg : T;
+    const int nseg = T / sl;
+    float tot = 0.0f;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        float s = 0.0f;
+        for (int i = lane; i < sl; i += 64) {
+            const int t = sgi * sl + i;
+            s += yr ? xr[t] * yr[t] : xr[t];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (seg_out && lane == 0) seg_out[(size_t)row * nseg + sgi] = s;
+        tot += s;
+    }
+    if (total && lane == 0) unsafeAtomicAdd(total + (row % C), alpha * tot);
+}
+
+// ----------------------------------------------------------------------------- MFCC (Encoder_2019)
+__global__ __launch_bounds__(256) void mfcc_kernel(const float* __restrict__ x, const float* __restrict__ mel,
+                                                   float* __restrict__ out, int T, int frames, int n_mel,
+                                                   int n_keep, int C_out) {
+    constexpr int FL = 400, STEP = 160, NB = 201;
+    __shared__ float xw[FL], cs[FL], sn[FL], mag[NB + 3], lm[128];
+    const int b = blockIdx.y, fr = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (size_t)b * T;
+    for (int n = tid; n < FL; n += 256) {
+        const int t = fr * STEP + n;
+        const float w = 0.5f - 0.5f * cospif(2.0f * n / FL);            // periodic hann (tf hann_window)
+        xw[n] = (t < T) ? xr[t] * w : 0.0f;                              // pad_end=True: zeros
+        cs[n] = cospif(2.0f * n / FL);
+        sn[n] = sinpif(2.0f * n / FL);
+    }
+    __syncthreads();
+    if (tid < NB) {
+        float re = 0.0f, im = 0.0f;
+        int m = 0;                                                       // (k*n) mod FL
+        for (int n = 0; n < FL; ++n) {
+            re = fmaf(xw[n], cs[m], re);
+            im = fmaf(xw[n], sn[m], im);
+            m += tid;
+            if (m >= FL) m -= FL;
+        }
+        mag[tid] = sqrtf(re * re + im * im);
+    }
+    __syncthreads();
+    if (tid < n_mel) {
+        float acc = 0.0f;
+        for (int k = 0; k < NB; ++k) acc = fmaf(mag[k], mel[(size_t)k * n_mel + tid], acc);
+        lm[tid] = logf(acc + 1e-6f);
+    }
+    __syncthreads();
+    if (tid < C_out) {
+        float v = 0.0f;
+        if (tid < n_keep) {
+            float acc = 0.0f;
+            for (int j = 0; j < n_mel; ++j) acc = fmaf(lm[j], cospif((float)tid * (2 * j + 1) / (2.0f * n_mel)), acc);
+            v = 2.0f * acc * rsqrtf(2.0f * n_mel);                       // tf dct type 2, then * rsqrt(2N)
+        }
+        out[((size_t)b * C_out + tid) * frames + fr] = v;
+    }
+}
+
 // ----------------------------------------------------------------------------- relu/BN backward
 __global__ void bn_relu_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ r,
                                    const float* __restrict__ scale, float* __restrict__ dz, int C, int T,
@@ -410,17 +481,27 @@ extern "C" int vqw_conv_cin1_wgrad(const float* x, const float* dout, float* dw,
 extern "C" int vqw_rowsum(const float* x, const float* y, float* seg_out, float* total, float alpha, int B,
                           int C, int T, int seg, vqw_stream_t s) {
     VQW_CHECK(x && (seg_out || total), "vqw_rowsum: null pointer");
-    VQW_CHECK(B > 0 && C > 0 && T > 0 && T % 4 == 0, "vqw_rowsum: T=%d must be a positive multiple of 4", T);
-    VQW_CHECK((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (!y || (reinterpret_cast<uintptr_t>(y) & 15u) == 0), "vqw_rowsum: inputs must be 16-byte aligned");
-    int lps = 0;
-    if (seg_out) {
-        VQW_CHECK(seg >= 4 && seg % 4 == 0 && T % seg == 0, "vqw_rowsum: seg=%d must divide T and be a multiple of 4", seg);
-        lps = seg / 4;
-        VQW_CHECK(lps <= 64 && (lps & (lps - 1)) == 0, "vqw_rowsum: seg/4=%d must be a power of two <= 64", lps);
-    }
+    VQW_CHECK(B > 0 && C > 0 && T > 0, "vqw_rowsum: bad shape");
     const int rows = B * C;
-    hipLaunchKernelGGL(rowsum_kernel, dim3(vqw_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, x, y, seg_out, total, alpha, rows, C, T, lps);
+    if (seg_out) VQW_CHECK(seg >= 1 && T % seg == 0, "vqw_rowsum: seg=%d must divide T=%d", seg, T);
+    int lps = (seg_out && seg % 4 == 0) ? seg / 4 : 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (!y || (reinterpret_cast<uintptr_t>(y) & 15u) == 0);
+    const bool fast = aligned && T % 4 == 0 && (!seg_out || (lps >= 1 && lps <= 64 && (lps & (lps - 1)) == 0));
+    if (fast)
+        hipLaunchKernelGGL(rowsum_kernel, dim3(vqw_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, x, y, seg_out, total, alpha, rows, C, T, lps);
+    else
+        hipLaunchKernelGGL(rowsum_general_kernel, dim3(vqw_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)s, x, y, seg_out, total, alpha, rows, C, T, seg_out ? seg : 0);
     VQW_LAUNCH_CHECK("vqw_rowsum");
+    return 0;
+}
+
+extern "C" int vqw_mfcc(const float* x, const float* mel, float* out, int B, int T, int frames, int n_mel, int n_keep,
+                        int C_out, vqw_stream_t s) {
+    VQW_CHECK(x && mel && out, "vqw_mfcc: null pointer");
+    VQW_CHECK(B > 0 && T > 0 && frames == (T + 159) / 160, "vqw_mfcc: frames must be ceil(T/160)");
+    VQW_CHECK(n_mel >= 1 && n_mel <= 128 && n_keep >= 1 && n_keep <= n_mel && C_out >= n_keep && C_out <= 256, "vqw_mfcc: bad n_mel / n_keep / C_out");
+    hipLaunchKernelGGL(mfcc_kernel, dim3(frames, B), dim3(256), 0, (hipStream_t)s, x, mel, out, T, frames, n_mel, n_keep, C_out);
+    VQW_LAUNCH_CHECK("vqw_mfcc");
     return 0;
 }
 

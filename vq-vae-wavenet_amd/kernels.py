@@ -63,6 +63,8 @@ def conv_gemm(*, x0, w, out0, B, T_in, T_out, M, C0, taps, x1=None, C1=0, in_str
             _need(out1, B * (M - m0) * Ts, 'out1')
         if save0 is not None:
             _need(save0, B * M * Ts, 'save0')
+        if aux1 is not None:
+            _need(aux1, B * M * Ts, 'aux1')
     if bias is not None and epilogue != EPI_GATE:
         _need(bias, M, 'bias')
     if scale is not None:
@@ -177,6 +179,16 @@ def bn_relu_bwd(dx, r, scale, dz):
     if r is not None:
         _need(r, dx.numel(), 'r')
     L.check(L.lib().vqw_bn_relu_bwd(L.ptr(dx), L.ptr(r), L.ptr(scale), L.ptr(dz), B, Cc, T, L.stream()))
+
+
+def mfcc(x, mel, out, *, n_keep=13):
+    """x [B][T], mel [201][n_mel] -> out [B][C_out][ceil(T/160)] (channels >= n_keep zeroed)."""
+    B, T = x.shape
+    _, C_out, frames = out.shape
+    L.require_cuda(x, mel, out)
+    if mel.shape[0] != 201:
+        raise ValueError('mel must be [201][n_mel]')
+    L.check(L.lib().vqw_mfcc(L.ptr(x), L.ptr(mel), L.ptr(out), B, T, frames, mel.shape[1], n_keep, C_out, L.stream()))
 
 
 def transpose(src, dst, batch, rows, cols):

@@ -17,7 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import kernels as K
-from .encoders import EncoderMagenta
+from .encoders import Encoder2019, EncoderMagenta
 
 BN_EPS = 1e-3  # Keras BatchNormalization default epsilon
 
@@ -52,7 +52,7 @@ class VQVAE:
 
     def __init__(self, model_cfg, wavenet_cfg, num_speakers, device='cuda', seed=0):
         self.enc = model_cfg.get('encoder', '64')
-        if self.enc not in ('64', 'Magenta'):     # '2019' (MFCC front end): not built yet
+        if self.enc not in ('64', 'Magenta', '2019'):
             raise NotImplementedError('encoder %s not implemented' % self.enc)
         self.m, self.w = model_cfg, wavenet_cfg
         self.dev = torch.device(device)
@@ -66,7 +66,7 @@ class VQVAE:
         if not self.use_vq or self.Cs <= 0:
             raise NotImplementedError('this build implements the default use_vq=true, speaker_embedding>0 path')
         self.Cc = self.D + self.Cs
-        self.magenta = EncoderMagenta(self.D) if self.enc == 'Magenta' else None
+        self.magenta = {'Magenta': EncoderMagenta, '2019': Encoder2019}[self.enc](self.D) if self.enc != '64' else None
         w = wavenet_cfg
         self.dil = list(w['dilation_rates'])
         self.L = len(self.dil)
@@ -159,7 +159,7 @@ class VQVAE:
             P['enc_w6'].copy_(glorot((F, D), 1, F, D))
             P['bn_gamma'].fill_(1.0)
         else:
-            self.magenta.init(P, uus)
+            self.magenta.init(P, uus if self.enc == 'Magenta' else glorot)
         P['embedding'].copy_(uus((self.Kc, D), self.Kc, 1.7))                       # model.py:47-49
         P['pre_w'].copy_(uus((self.pre_k, R), self.pre_k, 1.0))                     # wavenet_ops.py:69
         P['skip0_w'].copy_(uus((R, S), R, 1.0))
@@ -258,10 +258,13 @@ class VQVAE:
         key = (B, T)
         if key in self._ws:
             return self._ws[key]
-        if T % 64 != 0:
-            raise ValueError('length must be a multiple of 64 for Encoder_64 (got %d)' % T)
+        if self.enc == '64':
+            if T % 64 != 0:
+                raise ValueError('length must be a multiple of 64 for Encoder_64 (got %d)' % T)
+            Tz = T // 64
+        else:
+            Tz = self.magenta.latent_len(T)
         dev, F, D, R, S, Q, L = self.dev, self.F, self.D, self.R, self.S, self.Q, self.L
-        Tz = T // 64
         e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
         ws = {'B': B, 'T': T, 'Tz': Tz, 'ratio': T // Tz}
         ws['Tl'] = [T // (2 ** (i + 1)) for i in range(6)]
@@ -312,7 +315,7 @@ class VQVAE:
         """encoder.py:13-26 + model.py:57-74 + decoder_ops.py:39-43 -> ws['cond'] [B][Cc][Tz]."""
         P, F, D, B, T = self.P, self.F, self.D, ws['B'], ws['T']
         if self.enc != '64':
-            self.magenta.forward(x, ws, P, save)
+            self.magenta.forward(x, ws, P, self.T, save)
             self._quantise(spk, ws)
             return
         self._bn_affine(ws)
