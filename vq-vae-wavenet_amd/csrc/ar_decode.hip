@@ -14,6 +14,7 @@
 
 #include <vector>
 
+#include "ar_persist.h"
 #include "vqw_common.h"
 
 namespace {
@@ -324,6 +325,7 @@ struct vqw_ar_decoder {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     bool use_graph = true;
+    ArPersist* persist = nullptr;  // persistent single-launch generator (default model shapes)
 };
 
 namespace {
@@ -383,6 +385,7 @@ int launch_step(vqw_ar_decoder* h, hipStream_t st) {
 
 void free_all(vqw_ar_decoder* h) {
     if (!h) return;
+    if (h->persist) arp_destroy(h->persist);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (float* p : h->rings) (void)hipFree(p);
@@ -442,6 +445,11 @@ extern "C" int vqw_ar_decode_create(vqw_ar_decoder** out, const vqw_ar_weights* 
         free_all(h);
         return vqw_set_error("vqw_ar_decode_create: stream/event creation failed");
     }
+    if (arp_supported(w, batch)) {
+        const int rc = arp_create(&h->persist, w, h->dil.data(), h->gated_w.data(), h->gated_b.data(), h->out_w.data(),
+                                  h->out_b.data(), batch);
+        if (rc) { free_all(h); return rc; }
+    }
     *out = h;
     return vqw_ar_decode_reset(h, nullptr);
 }
@@ -450,6 +458,10 @@ extern "C" int vqw_ar_decode_reset(vqw_ar_decoder* h, vqw_stream_t s) {
     VQW_CHECK(h, "vqw_ar_decode_reset: null handle");
     hipStream_t st = (hipStream_t)s;
     const size_t B = h->B;
+    if (h->persist) {
+        const int rc = arp_reset(h->persist, st);
+        if (rc) return rc;
+    }
     HIPC(hipMemsetAsync(h->st, 0, sizeof(ArState), st));
     HIPC(hipMemsetAsync(h->prev, 0, B * sizeof(float), st));       // audio = zeros (generate.py:103)
     HIPC(hipMemsetAsync(h->xring, 0, B * h->w.pre_k * sizeof(float), st));
@@ -493,6 +505,15 @@ extern "C" int vqw_ar_decode_run(vqw_ar_decoder* h, const float* encoding, int T
         d.x0 = encoding; d.w = (l < L) ? h->cond_w[l] : w.post1_cond_w; d.out0 = h->condenc[l];
         const int rc = vqw_conv_gemm(&d, st);
         if (rc) return rc;
+    }
+    if (h->persist) {   // one launch for the whole run; waits for completion to report a spin-wait timeout
+        int rc = arp_run(h->persist, h->condenc.data(), Tz, ratio, n_steps, mode, uniforms, audio, indices, probs_last, st);
+        if (rc) return rc;
+        rc = arp_error(h->persist, st);
+        if (rc) return vqw_set_error("vqw_ar_decode_run: persistent kernel %s", rc > 0 ? "timed out waiting for a workgroup" : "failed");
+        HIPC(hipEventRecord(h->ev_out, st));
+        HIPC(hipStreamWaitEvent(user, h->ev_out, 0));
+        return 0;
     }
     // run parameters -> device state (step / run_base live on the device)
     ArState hs;
