@@ -110,16 +110,16 @@ __device__ __forceinline__ void gather(const Ctx& c, const u64* src, int n, unsi
 __device__ __forceinline__ void gather_taps(const Ctx& c, const u64* ring, int depth, int n, int ks, int dil, int t,
                                             float* dst) {
     for (int i = c.tid; i < n; i += 256) {
-        u64 g[VQW_MAX_TAPS];
+        u64 g[4];
 #pragma unroll
-        for (int j = 0; j < VQW_MAX_TAPS; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int tau = t - (ks - 1 - j) * dil;
             g[j] = (j < ks && tau >= 0)
                        ? __hip_atomic_load(ring + (size_t)(tau % depth) * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                        : 0ull;
         }
 #pragma unroll
-        for (int j = 0; j < VQW_MAX_TAPS; ++j) {
+        for (int j = 0; j < 4; ++j) {
             if (j < ks) {
                 const int tau = t - (ks - 1 - j) * dil;
                 float v = 0.0f;
@@ -154,30 +154,50 @@ __device__ __forceinline__ void block_sum(const Ctx& c, float (&v)[NJ][PB], int 
     __syncthreads();
 }
 
+// Workgroup bi owns CPB = 8 consecutive channels; thread (cg = tid/32, kl = tid%32) works for channel
+// c = bi*CPB + cg on rows k = kl + 32 i, so every dot product is finished by a 32-lane shuffle
+// reduction and the per-channel state (cur, skip accumulators) lives in the kl == 0 thread.
+// Fewer, fatter workgroups make every all-gather cheaper (R/8 producers instead of R).
+constexpr int CPB = 8;
+constexpr int RLMAX = 8;     // rows per lane for R <= 256
+constexpr int KSMAX = 4;     // taps of the dilated conv handled by the persistent kernel
+
+__device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes of a half wave
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+template <int TB>   // compile-time bound of the batch rows (register arrays stay small for B = 1)
 __global__ __launch_bounds__(256, 1) void ar_persist_kernel(const PArgs a) {
     extern __shared__ float lds[];
-    const int c0 = blockIdx.x, tid = threadIdx.x;
+    const int bi = blockIdx.x, tid = threadIdx.x;
+    const int cg = tid >> 5, kl = tid & 31;
+    const int c = bi * CPB + cg;                       // this thread's channel
     const int B = a.B, R = a.R, S = a.S, Q = a.Q, L = a.L, ks = a.ks, nS = a.nS, nQ = a.nQ;
+    const int RL = R / 32;                             // rows per lane (R % 32 == 0)
     // LDS carve
     float* xs = lds;                                   // [max(ks*B*R, B*S, B*Q)]
     int xmax = ks * B * R;
     if (B * S > xmax) xmax = B * S;
     if (B * Q > xmax) xmax = B * Q;
-    float* red = xs + xmax;                            // [4][PJ*PB]
-    float* res = red + 4 * PJ * PB;                    // [PJ*PB]
-    float* xh = res + PJ * PB;                         // [B][pre_k]
+    float* red = xs + xmax;                            // scratch of the sampler
+    float* xh = red + 5 * PJ * PB;                     // [B][pre_k]
     float* misc = xh + B * a.pre_k;                    // [64]
     int* fail = reinterpret_cast<int*>(misc + 60);
-    Ctx cx{tid, tid & 63, tid >> 6, red, res, fail};
+    Ctx cx{tid, tid & 63, tid >> 6, red, red + 4 * PJ * PB, fail};
     if (tid == 0) *fail = 0;
     for (int i = tid; i < B * a.pre_k; i += 256) xh[i] = a.xhist[i];
     __syncthreads();
 
     const int t0 = a.state[0];
     const int PH = 2 * L + 4;
-    float cur[PB], skipacc[4][PB], prevs[PB];
+    float cur[TB], skipacc[4][TB], prevs[TB];
 #pragma unroll
-    for (int b = 0; b < PB; ++b) prevs[b] = (b < B) ? a.prev[b] : 0.0f;
+    for (int b = 0; b < TB; ++b) { prevs[b] = (b < B) ? a.prev[b] : 0.0f; cur[b] = 0.0f; }
 
     for (int it = 0; it < a.n_steps; ++it) {
         const int t = t0 + it;
@@ -185,223 +205,183 @@ __global__ __launch_bounds__(256, 1) void ar_persist_kernel(const PArgs a) {
         const unsigned ttag = (unsigned)t + 1u;
         int frame = t / a.ratio;
         if (frame >= a.Tz) frame = a.Tz - 1;
-        // ---------------- preprocess: x_in(t) = mu_law_encode(previous sample); causal k=pre_k conv, column c0
+        // ---------------- preprocess: x_in(t) = mu_law_encode(previous sample); causal conv, lane kl = tap kl
         if (tid < B) xh[tid * a.pre_k + (t % a.pre_k)] = p_mu_enc(prevs[tid]);
         __syncthreads();
-        if (tid < B) {
-            float acc = a.preb[c0];
-            const float* w = a.prew + (size_t)c0 * a.pre_k;
-            for (int j = 0; j < a.pre_k; ++j) {
-                const int tau = t - (a.pre_k - 1 - j);
-                const int slot = ((tau % a.pre_k) + a.pre_k) % a.pre_k;
-                acc = fmaf(w[j], xh[tid * a.pre_k + slot], acc);
-            }
-            res[tid] = acc;
-        }
-        __syncthreads();
+        {
+            const float* w = a.prew + (size_t)c * a.pre_k;
 #pragma unroll
-        for (int b = 0; b < PB; ++b) cur[b] = (b < B) ? res[b] : 0.0f;
-        if (tid < B) publish(a.layers[0].ex_cur + ((size_t)(t % a.layers[0].depth) * B + tid) * R + c0, ttag, cur[tid]);
-        __syncthreads();
+            for (int b = 0; b < TB; ++b) {
+                if (b < B) {
+                    float acc = 0.0f;
+                    for (int j = kl; j < a.pre_k; j += 32) {
+                        const int tau = t - (a.pre_k - 1 - j);
+                        const int slot = ((tau % a.pre_k) + a.pre_k) % a.pre_k;
+                        acc = fmaf(w[j], xh[b * a.pre_k + slot], acc);
+                    }
+                    cur[b] = half_sum(acc) + a.preb[c];
+                    if (kl == 0) publish(a.layers[0].ex_cur + ((size_t)(t % a.layers[0].depth) * B + b) * R + c, ttag, cur[b]);
+                }
+            }
+        }
 
         for (int l = 0; l < L; ++l) {
             const PLayer& ly = a.layers[l];
-            // ---------------- gate phase: gather cur_l(t), cur_l(t-d), cur_l(t-2d) -> gated[c0]
-            // weights first: they do not depend on the hop, so their L2 / Infinity-Cache round trip
-            // overlaps the wait for the granules (R <= 256: one row per thread and tap)
-            f32x2 gwr[VQW_MAX_TAPS];
-            float swr[4];
+            // ---------------- gate phase: weights first (their L2 / Infinity-Cache round trip overlaps the
+            // wait for the granules), then gather cur_l(t), cur_l(t-d), cur_l(t-2d)
+            f32x2 gwr[KSMAX][RLMAX];
             {
-                const float* gw = ly.gw + (size_t)c0 * ks * R * 2;
+                const float* gw = ly.gw + (size_t)c * ks * R * 2;
 #pragma unroll
-                for (int j = 0; j < VQW_MAX_TAPS; ++j)
-                    gwr[j] = (j < ks && tid < R) ? *reinterpret_cast<const f32x2*>(gw + ((size_t)j * R + tid) * 2) : f32x2{0, 0};
-                const float* sw = a.s0w + (size_t)c0 * R * nS;
+                for (int j = 0; j < KSMAX; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) swr[j] = (l == 0 && j < nS && tid < R) ? sw[(size_t)tid * nS + j] : 0.0f;
+                    for (int i = 0; i < RLMAX; ++i)
+                        gwr[j][i] = (j < ks && i < RL) ? *reinterpret_cast<const f32x2*>(gw + ((size_t)j * R + kl + 32 * i) * 2)
+                                                       : f32x2{0, 0};
             }
-            for (int j = 0; j < ks; ++j) {   // oldest tap first: only the last one (tau = t) can still be in flight
-                const int tau = t - (ks - 1 - j) * ly.dil;
-                float* dst = xs + (size_t)j * B * R;
-                if (tau >= 0) {
-                    gather(cx, ly.ex_cur + (size_t)(tau % ly.depth) * B * R, B * R, (unsigned)tau + 1u, dst, 0);
-                } else {
-                    for (int i = tid; i < B * R; i += 256) dst[i] = 0.0f;   // queues start filled with zeros
-                }
+            const float gb0 = ly.gb[c * 2], gb1 = ly.gb[c * 2 + 1];
+            float cf[TB], cgv[TB];      // condition projections of this frame: off the critical path
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const float* cb = ly.cond + ((size_t)(b < B ? b : 0) * 2 * R) * a.Tz + frame;
+                cf[b] = cb[(size_t)c * a.Tz];
+                cgv[b] = cb[(size_t)(R + c) * a.Tz];
             }
+            gather_taps(cx, ly.ex_cur, ly.depth, B * R, ks, ly.dil, t, xs);   // all first loads in flight together
             __syncthreads();
-            {
-                float acc[6][PB];   // [0]=filter, [1]=gate, [2..2+nS) = skip-start columns (layer 0 only)
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
+            for (int b = 0; b < TB; ++b) {
+                if (b < B) {
+                    float af = 0.0f, ag = 0.0f;
 #pragma unroll
-                    for (int b = 0; b < PB; ++b) acc[j][b] = 0.0f;
-                if (tid < R) {
-#pragma unroll
-                    for (int j = 0; j < VQW_MAX_TAPS; ++j) {
+                    for (int j = 0; j < KSMAX; ++j) {
                         if (j < ks) {
 #pragma unroll
-                            for (int b = 0; b < PB; ++b) {
-                                if (b < B) {
-                                    const float xv = xs[((size_t)j * B + b) * R + tid];
-                                    acc[0][b] = fmaf(gwr[j][0], xv, acc[0][b]);
-                                    acc[1][b] = fmaf(gwr[j][1], xv, acc[1][b]);
+                            for (int i = 0; i < RLMAX; ++i) {
+                                if (i < RL) {
+                                    const float xv = xs[((size_t)j * B + b) * R + kl + 32 * i];
+                                    af = fmaf(gwr[j][i][0], xv, af);
+                                    ag = fmaf(gwr[j][i][1], xv, ag);
                                 }
                             }
                         }
                     }
+                    af = half_sum(af);
+                    ag = half_sum(ag);
                     if (l == 0) {   // skip = linear(current)  (wavenet.py:127-128)
-                        const float* xc = xs + (size_t)(ks - 1) * B * R;
+                        const float* xc = xs + ((size_t)(ks - 1) * B + b) * R;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < 4; ++j) {
+                            float s0 = 0.0f;
+                            if (j < nS) {
 #pragma unroll
-                            for (int b = 0; b < PB; ++b)
-                                if (j < nS && b < B) acc[2 + j][b] = fmaf(swr[j], xc[(size_t)b * R + tid], acc[2 + j][b]);
+                                for (int i = 0; i < RLMAX; ++i)
+                                    if (i < RL) s0 = fmaf(a.s0w[((size_t)c * R + kl + 32 * i) * nS + j], xc[kl + 32 * i], s0);
+                                s0 = half_sum(s0);
+                            }
+                            skipacc[j][b] = (j < nS) ? s0 + a.s0b[c * nS + j] : 0.0f;
+                        }
+                    }
+                    if (kl == 0) {
+                        const float vf = af + gb0 + cf[b];
+                        const float vg = ag + gb1 + cgv[b];
+                        const float th = 1.0f - 2.0f / (__expf(2.0f * vf) + 1.0f);
+                        const float sg = 1.0f / (1.0f + __expf(-vg));
+                        publish(a.ex_g + (size_t)b * R + c, seq + 2 * l, th * sg);
                     }
                 }
-                block_sum<6>(cx, acc, l == 0 ? 2 + nS : 2, B);
             }
-            if (tid < B) {
-                const int b = tid;
-                const float* cb = ly.cond + ((size_t)b * 2 * R) * a.Tz + frame;
-                const float vf = res[b] + ly.gb[c0 * 2] + cb[(size_t)c0 * a.Tz];
-                const float vg = res[PB + b] + ly.gb[c0 * 2 + 1] + cb[(size_t)(R + c0) * a.Tz];
-                const float th = 1.0f - 2.0f / (__expf(2.0f * vf) + 1.0f);
-                const float sg = 1.0f / (1.0f + __expf(-vg));
-                publish(a.ex_g + (size_t)b * R + c0, seq + 2 * l, th * sg);
-            }
-            if (l == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int b = 0; b < PB; ++b)
-                        skipacc[j][b] = (j < nS && b < B) ? res[(2 + j) * PB + b] + a.s0b[c0 * nS + j] : 0.0f;
-            }
-            __syncthreads();
-            // ---------------- out phase: gather gated -> skip columns (private accumulators) + residual column
+            // ---------------- out phase: skip columns (private accumulators) + residual column
             const int ncol = (l + 1 < L) ? nS + 1 : nS;     // net of the last layer is unused
-            float owr[5];
-            {
-                const float* ow = ly.ow + (size_t)c0 * R * (nS + 1);
+            float owr[5][RLMAX], obr[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) owr[j] = (j < ncol && tid < R) ? ow[(size_t)tid * (nS + 1) + j] : 0.0f;
-            }
-            gather(cx, a.ex_g, B * R, seq + 2 * l, xs, 0);
-            __syncthreads();
+            for (int j = 0; j < 5; ++j) obr[j] = (j < ncol) ? ly.ob[c * (nS + 1) + j] : 0.0f;
             {
-                float acc[5][PB];
+                const float* ow = ly.ow + (size_t)c * R * (nS + 1);
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
 #pragma unroll
-                    for (int b = 0; b < PB; ++b) acc[j][b] = 0.0f;
-                if (tid < R) {
-#pragma unroll
-                    for (int j = 0; j < 5; ++j)
-#pragma unroll
-                        for (int b = 0; b < PB; ++b)
-                            if (j < ncol && b < B) acc[j][b] = owr[j] * xs[(size_t)b * R + tid];
-                }
-                block_sum<5>(cx, acc, ncol, B);
+                    for (int i = 0; i < RLMAX; ++i)
+                        owr[j][i] = (j < ncol && i < RL) ? ow[(size_t)(kl + 32 * i) * (nS + 1) + j] : 0.0f;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int b = 0; b < PB; ++b)
-                    if (j < nS && b < B) skipacc[j][b] += res[j * PB + b] + ly.ob[c0 * (nS + 1) + j];
-            if (l + 1 < L) {
-#pragma unroll
-                for (int b = 0; b < PB; ++b)
-                    if (b < B) cur[b] += res[nS * PB + b] + ly.ob[c0 * (nS + 1) + nS];
-                const PLayer& nx = a.layers[l + 1];
-                if (tid < B) publish(nx.ex_cur + ((size_t)(t % nx.depth) * B + tid) * R + c0, ttag, cur[tid]);
-            }
+            __syncthreads();   // every thread is done with xs (gate inputs)
+            gather(cx, a.ex_g, B * R, seq + 2 * l, xs, 0);
             __syncthreads();
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                if (b < B) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        if (j < ncol) {
+                            float s = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < RLMAX; ++i)
+                                if (i < RL) s = fmaf(owr[j][i], xs[(size_t)b * R + kl + 32 * i], s);
+                            s = half_sum(s) + obr[j];
+                            if (j < nS) {
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj)
+                                    if (jj == j) skipacc[jj][b] += s;
+                            } else {
+                                cur[b] += s;
+                            }
+                        }
+                    }
+                    if (l + 1 < L && kl == 0) {
+                        const PLayer& nx = a.layers[l + 1];
+                        publish(nx.ex_cur + ((size_t)(t % nx.depth) * B + b) * R + c, ttag, cur[b]);
+                    }
+                }
+            }
+            __syncthreads();   // xs free again
         }
         // ---------------- postprocess1: relu(skip) -> 1x1 + condition  (wavenet.py:152-162)
-        if (tid < nS * B) {
-            const int j = tid / B, b = tid % B;
-            float v = 0.0f;
+        if (kl == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int b = 0; b < TB; ++b)
 #pragma unroll
-                for (int bb = 0; bb < PB; ++bb)
-                    if (jj == j && bb == b) v = skipacc[jj][bb];
-            publish(a.ex_s + (size_t)b * S + c0 + (size_t)j * R, seq + 2 * L, v);
-        }
-        float p1r[4][4];    // [row group i: k = tid + 256 i][column j]
-        {
-            const float* w = a.p1w + (size_t)c0 * S * nS;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = tid + 256 * i;
-                    p1r[i][j] = (k < S && j < nS) ? w[(size_t)k * nS + j] : 0.0f;
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (b < B && j < nS) publish(a.ex_s + (size_t)b * S + c + (size_t)j * R, seq + 2 * L, skipacc[j][b]);
         }
         gather(cx, a.ex_s, B * S, seq + 2 * L, xs, 1);
         __syncthreads();
         {
-            float acc[4][PB];
+            const float* w = a.p1w + (size_t)c * S * nS;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int b = 0; b < TB; ++b) {
+                if (b < B) {
 #pragma unroll
-                for (int b = 0; b < PB; ++b) acc[j][b] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = tid + 256 * i;
-                if (k < S) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int b = 0; b < PB; ++b)
-                            if (j < nS && b < B) acc[j][b] = fmaf(p1r[i][j], xs[(size_t)b * S + k], acc[j][b]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < nS) {
+                            float s = 0.0f;
+                            for (int k = kl; k < S; k += 32) s = fmaf(w[(size_t)k * nS + j], xs[(size_t)b * S + k], s);
+                            s = half_sum(s);
+                            if (kl == 0) {
+                                const float v = s + a.p1b[c * nS + j] + a.cond1[((size_t)b * S + c + (size_t)j * R) * a.Tz + frame];
+                                publish(a.ex_h + (size_t)b * S + c + (size_t)j * R, seq + 2 * L + 1, v);
+                            }
+                        }
+                    }
                 }
             }
-            block_sum<4>(cx, acc, nS, B);
-        }
-        if (tid < nS * B) {
-            const int j = tid / B, b = tid % B;
-            const float v = res[j * PB + b] + a.p1b[c0 * nS + j] + a.cond1[((size_t)b * S + c0 + (size_t)j * R) * a.Tz + frame];
-            publish(a.ex_h + (size_t)b * S + c0 + (size_t)j * R, seq + 2 * L + 1, v);
         }
         __syncthreads();
         // ---------------- postprocess2: relu(h) -> logits  (wavenet.py:165-167)
-        float p2r[4][PJ];
-        {
-            const float* w = a.p2w + (size_t)c0 * S * nQ;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < PJ; ++j) {
-                    const int k = tid + 256 * i;
-                    p2r[i][j] = (k < S && j < nQ) ? w[(size_t)k * nQ + j] : 0.0f;
-                }
-        }
         gather(cx, a.ex_h, B * S, seq + 2 * L + 1, xs, 1);
         __syncthreads();
         {
-            float acc[PJ][PB];
+            const float* w = a.p2w + (size_t)c * S * nQ;
 #pragma unroll
-            for (int j = 0; j < PJ; ++j)
-#pragma unroll
-                for (int b = 0; b < PB; ++b) acc[j][b] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = tid + 256 * i;
-                if (k < S) {
-#pragma unroll
-                    for (int j = 0; j < PJ; ++j)
-#pragma unroll
-                        for (int b = 0; b < PB; ++b)
-                            if (j < nQ && b < B) acc[j][b] = fmaf(p2r[i][j], xs[(size_t)b * S + k], acc[j][b]);
+            for (int b = 0; b < TB; ++b) {
+                if (b < B) {
+                    for (int j = 0; j < nQ; ++j) {
+                        float s = 0.0f;
+                        for (int k = kl; k < S; k += 32) s = fmaf(w[(size_t)k * nQ + j], xs[(size_t)b * S + k], s);
+                        s = half_sum(s);
+                        if (kl == 0) publish(a.ex_l + (size_t)b * Q + c + (size_t)j * R, seq + 2 * L + 2, s + a.p2b[c * nQ + j]);
+                    }
                 }
             }
-            block_sum<PJ>(cx, acc, nQ, B);
-        }
-        if (tid < nQ * B) {
-            const int j = tid / B, b = tid % B;
-            publish(a.ex_l + (size_t)b * Q + c0 + (size_t)j * R, seq + 2 * L + 2, res[j * PB + b] + a.p2b[c0 * nQ + j]);
         }
         __syncthreads();
         // ---------------- softmax + decode (every workgroup redundantly: identical bits everywhere)
@@ -446,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void ar_persist_kernel(const PArgs a) {
             for (int q = tid; q < Q; q += 256) {
                 const float p = lg[q] * inv;
                 lg[q] = p;
-                if (c0 == 0 && a.probs_last && it == a.n_steps - 1) a.probs_last[(size_t)b * Q + q] = p;
+                if (bi == 0 && a.probs_last && it == a.n_steps - 1) a.probs_last[(size_t)b * Q + q] = p;
             }
             __syncthreads();
             if (tid == 0) {
@@ -464,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void ar_persist_kernel(const PArgs a) {
                 }
                 const float dec = p_mu_dec((float)idx);
                 misc[b] = dec;
-                if (c0 == 0) {
+                if (bi == 0) {
                     if (a.audio) a.audio[(size_t)b * a.n_steps + it] = dec;
                     if (a.indices) a.indices[(size_t)b * a.n_steps + it] = idx;
                 }
@@ -472,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void ar_persist_kernel(const PArgs a) {
             __syncthreads();
         }
 #pragma unroll
-        for (int b = 0; b < PB; ++b) prevs[b] = (b < B) ? misc[b] : 0.0f;
+        for (int b = 0; b < TB; ++b) prevs[b] = (b < B) ? misc[b] : 0.0f;
         if (*reinterpret_cast<volatile int*>(fail)) break;
         __syncthreads();
     }
@@ -482,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void ar_persist_kernel(const PArgs a) {
         if (tid == 0) atomicExch(a.state + 1, 1);
         return;
     }
-    if (c0 == 0) {
+    if (bi == 0) {
         for (int i = tid; i < B * a.pre_k; i += 256) a.xhist[i] = xh[i];
         if (tid < B) a.prev[tid] = prevs[tid];
         if (tid == 0) a.state[0] = t0 + a.n_steps;
@@ -534,11 +514,11 @@ bool arp_supported(const vqw_ar_weights* w, int batch) {
     if (w->R < 1 || w->S % w->R || w->Q % w->R) return false;
     const int nS = w->S / w->R, nQ = w->Q / w->R;
     if (nS < 1 || nS > 4 || nQ < 1 || nQ > PJ || batch > PB || w->pre_k > 60) return false;
-    if (w->R > 256 || w->S > 1024 || w->kernel_size > VQW_MAX_TAPS) return false;   // one weight row per thread and row group
+    if (w->R > 256 || w->R % 32 || w->kernel_size > KSMAX) return false;   // R/32 <= 8 weight rows per lane, 8 channels per workgroup
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return w->R <= cus;   // one resident workgroup per CU is what makes the spin-waits safe
+    return w->R / 8 <= cus;   // one resident workgroup per CU is what makes the spin-waits safe
 }
 
 int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const float* const* gated_w,
@@ -639,9 +619,11 @@ int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const f
     h->lds_bytes = (size_t)(xmax + 5 * PJ * PB + batch * w->pre_k + 64) * sizeof(float);
     if (h->lds_bytes < 96 * 1024) h->lds_bytes = 96 * 1024;   // > half of the 160 KiB: one workgroup per CU
     if (h->lds_bytes > 160 * 1024) return fail("LDS budget exceeded");
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ar_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)h->lds_bytes) != hipSuccess)
-        return fail("hipFuncSetAttribute failed");
+    const void* kfn[4] = {reinterpret_cast<const void*>(ar_persist_kernel<1>), reinterpret_cast<const void*>(ar_persist_kernel<2>),
+                          reinterpret_cast<const void*>(ar_persist_kernel<4>), reinterpret_cast<const void*>(ar_persist_kernel<8>)};
+    for (const void* f : kfn)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
+            return fail("hipFuncSetAttribute failed");
     *out = h;
     return 0;
 }
@@ -660,7 +642,11 @@ int arp_run(ArPersist* h, const float* const* condenc, int Tz, int ratio, int n_
     a.cond1 = condenc[L];
     a.Tz = Tz; a.ratio = ratio; a.mode = mode; a.n_steps = n_steps;
     a.uniforms = uniforms; a.audio = audio; a.indices = indices; a.probs_last = probs_last;
-    hipLaunchKernelGGL(ar_persist_kernel, dim3(h->w.R), dim3(256), h->lds_bytes, st, a);
+    const dim3 grid(h->w.R / 8), block(256);
+    if (h->B <= 1) hipLaunchKernelGGL(ar_persist_kernel<1>, grid, block, h->lds_bytes, st, a);
+    else if (h->B <= 2) hipLaunchKernelGGL(ar_persist_kernel<2>, grid, block, h->lds_bytes, st, a);
+    else if (h->B <= 4) hipLaunchKernelGGL(ar_persist_kernel<4>, grid, block, h->lds_bytes, st, a);
+    else hipLaunchKernelGGL(ar_persist_kernel<8>, grid, block, h->lds_bytes, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vqw_set_error("vqw_ar_decode_run(persistent): launch failed: %s", hipGetErrorString(e));
     return 0;
