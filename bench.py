@@ -92,6 +92,16 @@ class GateConvTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
 
 
+def hbm_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/round1_gate_conv_traffic.json, made by tools/pmc_traffic.py); None if absent."""
+    p = os.path.join(ROOT, 'profiles', 'round1_gate_conv_traffic.json')
+    if not os.path.exists(p):
+        return None
+    with open(p) as fh:
+        return json.load(fh).get('hbm_bytes')
+
+
 def log(*a):
     print('[bench]', *a, file=sys.stderr, flush=True)
 
@@ -230,7 +240,7 @@ def main():
             "loss": loss,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<2,2,GATE> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate)",
                          "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": hbm_traffic(),
                          "ms_per_launch": gate_ms, "flop_per_launch": flops_gate,
                          "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
         }

@@ -21,7 +21,7 @@ for name, d in (('FETCH_SIZE', sys.argv[1]), ('WRITE_SIZE', sys.argv[2])):
 fetch = out['FETCH_SIZE_KiB_per_launch'] * 1024 * 2      # gfx950: FETCH_SIZE counts 64 B per 128-B request
 write = out['WRITE_SIZE_KiB_per_launch'] * 1024
 out.update(hbm_read_bytes=fetch, hbm_write_bytes=write, hbm_bytes=fetch + write,
-           algorithmic_bytes=8 * 6656 * (256 + 4 * 256) * 4,   # read net (256 ch) + write gated, tanh, sigmoid... see DESIGN.md
+           algorithmic_bytes=8 * 6656 * (256 + 3 * 256) * 4 + 3 * 256 * 512 * 4,   # read net + write gated, tanh, sigmoid + weights
            note='gate conv B=8 T=6656 256->512 k=3 d=8, tile 22; reads x + weights, writes gated+tanh+sigmoid (3x256 ch)')
 json.dump(out, open('profiles/round1_gate_conv_traffic.json', 'w'), indent=1)
 print(json.dumps(out))
