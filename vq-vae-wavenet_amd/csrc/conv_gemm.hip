@@ -47,9 +47,11 @@ constexpr int BK = VQW_BK;  // channels per K-step
 struct ConvArgs {
     vqw_conv_desc d;
     int n_mt, n_nt, nwg;
+    int t_begin;  // first output column of this launch (a GEMM may be cut into a main and a tail launch)
     int H;       // GATE / GATE_BWD: half width
     int ratio;   // cond: T_out / cond_T
     int vec_ok;  // output rows allow aligned vector stores
+    int use_dma; // LDS-DMA pipeline for interior blocks (VQW_CONV_DMA=0 disables it)
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -102,9 +104,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     static_assert(EPI != VQW_EPI_GATE || MT == 2, "gate epilogue pairs two M tiles");
     constexpr bool GATE = (EPI == VQW_EPI_GATE);
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
-    float* const As = smem;
-    float* const Bs = smem + 2 * BK * BM;
+    // ONE LDS array (a second __shared__ object beside LDS-DMA traffic makes hipcc drain vmcnt before every
+    // ds_read); stage-major: stage s = weight image [BK][BM], then activation image [BK][BN].  The register
+    // pipeline uses stages 0-1, the LDS-DMA pipeline all three.
+    constexpr int NST = 3, STG = BK * (BM + BN);
+    __shared__ __attribute__((aligned(16))) float smem[NST * STG];
 
     const vqw_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     L /= a.n_mt;
     const int nt = L % a.n_nt;
     const int b = L / a.n_nt;
-    const int t0 = nt * BN;
+    const int t0 = a.t_begin + nt * BN;
     const int o0 = GATE ? mt * (BM / 2) : mt * BM;  // first output row / gated channel
     const int Ctot = d.C0 + d.C1;
     const int kchunks = Ctot / BK;
@@ -209,21 +213,20 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     // registers -> LDS, piece p
     auto piece_store = [&](int p, int buf) {
         if (p < NA) {
-            float* Ab = As + buf * BK * BM;
+            float* Ab = smem + buf * STG;
             const int idx = tid + p * 256;
-            if constexpr (GATE) {
+            if constexpr (GATE) {   // row image = [filter BM/2 | gate BM/2]
                 const int kk = idx / (BM / 8), u2 = idx % (BM / 8);
-                float* q = Ab + kk * BM + 8 * u2;
-                const f32x4 F = ra[2 * p], G = ra[2 * p + 1];
-                *reinterpret_cast<f32x4*>(q) = f32x4{F[0], G[0], F[1], G[1]};
-                *reinterpret_cast<f32x4*>(q + 4) = f32x4{F[2], G[2], F[3], G[3]};
+                float* q = Ab + kk * BM + 4 * u2;
+                *reinterpret_cast<f32x4*>(q) = ra[2 * p];
+                *reinterpret_cast<f32x4*>(q + BM / 2) = ra[2 * p + 1];
             } else {
                 const int kk = idx / (BM / 4), u = idx % (BM / 4);
                 *reinterpret_cast<f32x4*>(Ab + kk * BM + 4 * u) = ra[p];
             }
         } else {
             const int i = p - NA;
-            float* Bb = Bs + buf * BK * BN;
+            float* Bb = smem + buf * STG + BK * BM;
             const int idx = tid + i * 256;
             const int kk = idx / (BN / 4), u = idx % (BN / 4);
             f32x4 v = rb[i];
@@ -246,7 +249,10 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     // one k-step (2 channels) of operand fragments: lanes 0-31 take channel 2ks, lanes 32-63 2ks+1
     auto read_frags = [&](const float* Ab, const float* Bb, int ks, float (&av)[MT], float (&bv)[NT]) {
         const int kk = 2 * ks + lhi;
-        if constexpr (MT == 2) {
+        if constexpr (GATE) {           // filter row and gate row of the same channel: one ds_read2_b32
+            av[0] = Ab[kk * BM];
+            av[1] = Ab[kk * BM + BM / 2];
+        } else if constexpr (MT == 2) {
             const f32x2 t = *reinterpret_cast<const f32x2*>(Ab + kk * BM);
             av[0] = t[0]; av[1] = t[1];
         } else {
@@ -305,8 +311,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
         auto kstep = [&](auto mode_tag, int s) {
             constexpr int MODE = decltype(mode_tag)::value;
             const int buf = s & 1;
-            const float* Ab = As + buf * BK * BM + wm * (MT * 32) + MT * l31;
-            const float* Bb = Bs + buf * BK * BN + wn * (NT * 32) + NT * l31;
+            const float* Ab = smem + buf * STG + (GATE ? wm * 32 + l31 : wm * (MT * 32) + MT * l31);
+            const float* Bb = smem + buf * STG + BK * BM + wn * (NT * 32) + NT * l31;
             // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run;
             // sched_barrier pins that order (hipcc otherwise sinks the reads next to their use)
             float a0[MT], b0[NT], a1[MT], b1[NT];
@@ -358,6 +364,109 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
         if (s + 1 < nsteps) { kstep(std::integral_constant<int, 1>{}, s); ++s; }
         if (s < nsteps) kstep(std::integral_constant<int, 0>{}, s);
     };
+    // ---- LDS-DMA pipeline.  PMC on the register pipeline above (profiles/round1_gate_conv_pmc_sq.txt): MFMA busy
+    // 70 % with the waves parked at the vmcnt wait in front of their ds_writes -- one K-step (2048 MFMA cycles per
+    // wave, shared three ways) is not enough for a global load to land.  Here tile s+2 travels global -> LDS by
+    // buffer_load_dwordx4 ... lds (no VGPRs, no ds_write) into a third stage while tile s is multiplied and tile
+    // s+1 is already resident: two K-steps of latency budget.  Every wave issues its own 1-KiB pieces, one behind
+    // each MFMA group; a counted vmcnt (the next tile's pieces stay in flight) and a raw s_barrier retire tile s+1
+    // one phase before it is read.  Used by interior blocks of unit-stride convolutions with a full M tile.
+    auto k_loop_dma = [&]() {
+        constexpr int NDMA = A_F4 + B_F4;       // 1-KiB pieces per wave and K-step
+        static_assert(NDMA <= BK / 2, "one DMA piece per MFMA group");
+        constexpr int WAIT_NEXT = (NDMA & 0xF) | (0x7 << 4) | (0xF << 8) | ((NDMA >> 4) << 14);   // vmcnt(NDMA) only
+        constexpr int WAIT_ALL = 0 | (0x7 << 4) | (0xF << 8);                                     // vmcnt(0) only
+        const long wfloats = (long)(d.ntaps - 1) * d.w_tap_stride + (long)Ctot * d.ldw;
+        const __amdgpu_buffer_rsrc_t rsw = vqw_make_rsrc(d.w, (unsigned)(wfloats * 4));
+        int va[A_F4], vb[B_F4];
+#pragma unroll
+        for (int q = 0; q < A_F4; ++q) {
+            const int f = (wid * A_F4 + q) * 256 + 4 * lane;
+            const int kk = f / BM, m = f % BM;
+            const int col = GATE ? ((m < BM / 2) ? o0 + m : a.H + o0 + (m - BM / 2)) : o0 + m;
+            va[q] = (kk * d.ldw + col) * 4;
+        }
+#pragma unroll
+        for (int q = 0; q < B_F4; ++q) {
+            const int f = (wid * B_F4 + q) * 256 + 4 * lane;
+            vb[q] = ((f / BN) * d.T_in + (f % BN)) * 4;
+        }
+        int ld_tap = next_tap(-1), ld_kc = 0;
+        auto advance = [&]() {
+            ld_kc += BK;
+            if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
+        };
+        auto dma = [&](int q, int st) {   // piece q of tile (ld_tap, ld_kc) -> stage st
+            if (q < A_F4) {
+                const int soff = (int)(((long)ld_tap * d.w_tap_stride + (long)ld_kc * d.ldw) * 4);
+                vqw_buf_load_lds16(rsw, smem + st * STG + (wid * A_F4 + q) * 256, va[q], soff);
+            } else {
+                const int i = q - A_F4;
+                const bool first = ld_kc < d.C0;
+                const int soff = ((first ? ld_kc : ld_kc - d.C0) * d.T_in + t0 + d.tap_shift[ld_tap]) * 4;
+                vqw_buf_load_lds16(first ? rs0 : rs1, smem + st * STG + BK * BM + (wid * B_F4 + i) * 256, vb[i], soff);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) dma(q, 0);
+        advance();
+        if (nsteps > 1) {
+#pragma unroll
+            for (int q = 0; q < NDMA; ++q) dma(q, 1);
+            advance();
+            __builtin_amdgcn_s_waitcnt(WAIT_NEXT);
+        } else {
+            __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+        }
+        __builtin_amdgcn_s_barrier();
+        // MODE 1: tile s+2 is issued into stage nxt and stays in flight across the barrier; 0: nothing left to issue
+        auto kstep = [&](auto mode_tag, int cur, int nxt) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            const float* Ab = smem + cur * STG + (GATE ? wm * 32 + l31 : wm * (MT * 32) + MT * l31);
+            const float* Bb = smem + cur * STG + BK * BM + wn * (NT * 32) + NT * l31;
+            float a0[MT], b0[NT], a1[MT], b1[NT];
+            read_frags(Ab, Bb, 0, a0, b0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ks += 2) {
+                read_frags(Ab, Bb, ks + 1, a1, b1);
+                SCHED_FENCE();
+                MMA_PRIO(1);
+                mma(a0, b0);
+                MMA_PRIO(0);
+                SCHED_FENCE();
+                if constexpr (MODE == 1) {
+                    if (ks < NDMA) dma(ks, nxt);
+                }
+                if (ks + 2 < BK / 2) read_frags(Ab, Bb, ks + 2, a0, b0);
+                SCHED_FENCE();
+                MMA_PRIO(1);
+                mma(a1, b1);
+                MMA_PRIO(0);
+                SCHED_FENCE();
+                if constexpr (MODE == 1) {
+                    if (ks + 1 < NDMA) dma(ks + 1, nxt);
+                }
+                SCHED_FENCE();
+            }
+            if constexpr (MODE == 1) {
+                advance();
+                __builtin_amdgcn_s_waitcnt(WAIT_NEXT);   // my pieces of tile s+1 have landed; tile s+2 stays in flight
+            } else {
+                __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            }
+            __builtin_amdgcn_s_barrier();                // everybody's pieces of tile s+1 have landed; stage cur is free
+        };
+        int s = 0, cur = 0;
+        for (; s + 2 < nsteps; ++s) {
+            const int nxt = (cur == 0) ? 2 : cur - 1;    // (cur + 2) % 3
+            kstep(std::integral_constant<int, 1>{}, cur, nxt);
+            cur = (cur == 2) ? 0 : cur + 1;
+        }
+        for (; s < nsteps; ++s) {
+            kstep(std::integral_constant<int, 0>{}, cur, 0);
+            cur = (cur == 2) ? 0 : cur + 1;
+        }
+    };
     bool all_interior = true;
     for (int j = 0; j < d.ntaps; ++j) {
         if (!((act >> j) & 1u)) continue;
@@ -365,7 +474,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
         const int hi = d.in_stride * (t0 + BN - 1) + d.tap_shift[j] + (d.in_stride - 1);  // last element touched
         all_interior = all_interior && (lo >= 0) && (hi < d.T_in);
     }
-    if (all_interior) k_loop(std::true_type{});
+    const bool full_m = GATE ? (o0 + BM / 2 <= a.H) : (o0 + BM <= d.M);
+    if (all_interior && d.in_stride == 1 && !d.in_relu && full_m && nsteps > 0 && a.use_dma) k_loop_dma();
+    else if (all_interior) k_loop(std::true_type{});
     else k_loop(std::false_type{});
 
     // ------------------------------------------------------------------ epilogue
@@ -486,12 +597,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
 }
 
 template <int MT, int NT>
-int launch_cfg(ConvArgs& a, hipStream_t st) {
+int launch_cfg(ConvArgs& a, hipStream_t st, int t_begin, int t_cols) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     const vqw_conv_desc& d = a.d;
     const bool gate = d.epilogue == VQW_EPI_GATE;
     a.n_mt = gate ? vqw_cdiv(a.H, BM / 2) : vqw_cdiv(d.M, BM);
-    a.n_nt = vqw_cdiv(d.T_out, BN);
+    a.n_nt = vqw_cdiv(t_cols, BN);
+    a.t_begin = t_begin;
     a.nwg = a.n_mt * a.n_nt * d.B;
     dim3 grid(a.nwg), block(256);
     switch (d.epilogue) {
@@ -578,6 +690,8 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
                 (!d.save0 || aligned16(d.save0)) && (!d.save1 || aligned16(d.save1)))
                    ? 1 : 0;
 
+    static const int dma_env = [] { const char* e = getenv("VQW_CONV_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
+    a.use_dma = dma_env;
     hipStream_t st = static_cast<hipStream_t>(s);
     int tile = d.tile;
     if (tile == 0) {
@@ -589,13 +703,47 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
         const int ntile = 2;
         tile = 10 * mt + ntile;
     }
-    switch (tile) {
-        case 24: return launch_cfg<2, 4>(a, st);
-        case 22: return launch_cfg<2, 2>(a, st);
-        case 21: return launch_cfg<2, 1>(a, st);
-        case 14: return launch_cfg<1, 4>(a, st);
-        case 12: return launch_cfg<1, 2>(a, st);
-        case 11: return launch_cfg<1, 1>(a, st);
-        default: return vqw_set_error("vqw_conv_gemm: unsupported tile %d", tile);
+    // A GEMM whose block count leaves a thin last round (B*T = 13*2^12 makes every tiling a multiple of 13
+    // blocks; measured on the gate conv: two full rounds of 768 blocks, then 128 blocks alone on a mostly idle
+    // chip = 16 % of the kernel) is cut in two launches: whole rounds of the chosen tile over the first columns,
+    // the remaining columns with tiles half as wide, which spread over all CUs.  Explicit form of `tile`:
+    // main + 100*tail_tile + 10000*(main-tile columns given to the tail); VQW_CONV_TAIL=0 disables the auto cut.
+    static const int tail_env = [] { const char* e = getenv("VQW_CONV_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int main_tile = tile % 100;
+    int tail_tile = (tile / 100) % 100, tail_nt = tile / 10000;
+    const int mtm = main_tile / 10, ntm = main_tile % 10;
+    if (mtm < 1 || mtm > 2 || (ntm != 1 && ntm != 2 && ntm != 4)) return vqw_set_error("vqw_conv_gemm: unsupported tile %d", tile);
+    const int BNm = 64 * ntm;
+    const int n_nt = vqw_cdiv(d.T_out, BNm);
+    if (tail_tile == 0 && tail_env && ntm > 1) {
+        const int occ = (main_tile == 22) ? 3 : (main_tile == 24 || main_tile == 14) ? 2 : (main_tile == 11) ? 6 : 4;
+        const int n_mt = (d.epilogue == VQW_EPI_GATE) ? vqw_cdiv(a.H, 32 * mtm) : vqw_cdiv(d.M, 64 * mtm);
+        const long slots = (long)cus * occ, per_col = (long)n_mt * d.B, nblk = per_col * n_nt;
+        const long rem = nblk % slots;
+        if (nblk > slots && rem > 0 && rem * 10 < slots * 7) {
+            tail_nt = (int)((rem + per_col - 1) / per_col);
+            tail_tile = 10 * mtm + ntm / 2;
+        }
     }
+    auto launch = [&](int t, int t_begin, int t_cols) -> int {
+        switch (t) {
+            case 24: return launch_cfg<2, 4>(a, st, t_begin, t_cols);
+            case 22: return launch_cfg<2, 2>(a, st, t_begin, t_cols);
+            case 21: return launch_cfg<2, 1>(a, st, t_begin, t_cols);
+            case 14: return launch_cfg<1, 4>(a, st, t_begin, t_cols);
+            case 12: return launch_cfg<1, 2>(a, st, t_begin, t_cols);
+            case 11: return launch_cfg<1, 1>(a, st, t_begin, t_cols);
+            default: return vqw_set_error("vqw_conv_gemm: unsupported tile %d", t);
+        }
+    };
+    if (tail_tile == 0 || tail_nt <= 0 || tail_nt >= n_nt) return launch(main_tile, 0, d.T_out);
+    const int t_main = (n_nt - tail_nt) * BNm;
+    const int rc = launch(main_tile, 0, t_main);
+    if (rc) return rc;
+    return launch(tail_tile, t_main, d.T_out - t_main);
 }

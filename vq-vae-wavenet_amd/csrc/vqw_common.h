@@ -28,6 +28,15 @@ __device__ __forceinline__ f32x4 vqw_buf_load4(__amdgpu_buffer_rsrc_t r, int vof
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0);
     return __builtin_bit_cast(f32x4, v);
 }
+// LDS-DMA: 16 bytes per lane global -> LDS with no VGPR in between (buffer_load_dwordx4 ... lds).  The 64 lanes
+// of a wave fill 1 KiB starting at the wave-uniform `lds_dst` (lane i lands at +16 i); the SOURCE address is per
+// lane.  Counts on vmcnt.  (The builtin only exists in the device pass; called directly from a template kernel it
+// makes the host pass drop the kernel's launch stub without a diagnostic, hence this wrapper and the guard.)
+__device__ __forceinline__ void vqw_buf_load_lds16(__amdgpu_buffer_rsrc_t r, float* lds_dst, int voff_bytes, int soff_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
+#endif
+}
 #endif
 
 int vqw_set_error(const char* fmt, ...);
