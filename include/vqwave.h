@@ -85,8 +85,9 @@ typedef struct vqw_conv_desc {
                                                   output rows have T_store elements      */
     int32_t cond_T;   /* 0 = none; cond[b][row][t / (T_out/cond_T)] is added             */
     int32_t tile;     /* 0 = auto; else 10*MT+NT (per-wave 32x32 tile counts), optionally
-                         + 100*tail_tile + 10000*n: the last n main-tile columns of every
-                         row run as a second launch with tail_tile (load balance)          */
+                         + 10000*n: the last n main-tile columns of every row are computed
+                         by tiles half as wide at the end of the same grid (load balance;
+                         chosen automatically when n is not given)                        */
     int64_t cond_bstride; /* batch stride of cond in floats                              */
     int64_t w_tap_stride; /* floats between consecutive taps of w; 0 = (C0+C1)*ldw       */
     const float *x0, *x1, *w, *bias, *cond, *scale, *shift, *aux0, *aux1;

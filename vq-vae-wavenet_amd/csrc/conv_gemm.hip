@@ -44,10 +44,13 @@ constexpr int BK = VQW_BK;  // channels per K-step
 #define MMA_PRIO(p) ((void)0)
 #endif
 
+struct BlockGrid {   // one rectangle of output tiles: all M tiles x n_nt column tiles from t_begin x all batch rows
+    int n_mt, n_nt, nwg, t_begin;
+};
+
 struct ConvArgs {
     vqw_conv_desc d;
-    int n_mt, n_nt, nwg;
-    int t_begin;  // first output column of this launch (a GEMM may be cut into a main and a tail launch)
+    BlockGrid main, tail;   // tail.nwg == 0: no tail tiles
     int H;       // GATE / GATE_BWD: half width
     int ratio;   // cond: T_out / cond_T
     int vec_ok;  // output rows allow aligned vector stores
@@ -95,8 +98,9 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rowp, int tb,
     }
 }
 
+// One output tile.  `smem` holds NST stages of BK*(BM+BN) floats (the caller's ONE LDS array).
 template <int MT, int NT, int EPI>
-__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_gemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem, const int bid, const BlockGrid g) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int A_F4 = (BK * BM / 4) / 256;  // float4 per thread, weight tile
     constexpr int B_F4 = (BK * BN / 4) / 256;  // float4 per thread, activation tile
@@ -104,11 +108,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     static_assert(EPI != VQW_EPI_GATE || MT == 2, "gate epilogue pairs two M tiles");
     constexpr bool GATE = (EPI == VQW_EPI_GATE);
 
-    // ONE LDS array (a second __shared__ object beside LDS-DMA traffic makes hipcc drain vmcnt before every
-    // ds_read); stage-major: stage s = weight image [BK][BM], then activation image [BK][BN].  The register
-    // pipeline uses stages 0-1, the LDS-DMA pipeline all three.
-    constexpr int NST = 3, STG = BK * (BM + BN);
-    __shared__ __attribute__((aligned(16))) float smem[NST * STG];
+    // stage-major LDS: stage s = weight image [BK][BM], then activation image [BK][BN].  The register pipeline
+    // uses stages 0-1, the LDS-DMA pipeline all three.
+    constexpr int STG = BK * (BM + BN);
 
     const vqw_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -118,12 +120,12 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
 
     // block -> (m tile, n tile, batch); m fastest so co-scheduled blocks share the
     // activation panel in one XCD's L2.
-    int L = vqw_xcd_remap(blockIdx.x, a.nwg);
-    const int mt = L % a.n_mt;
-    L /= a.n_mt;
-    const int nt = L % a.n_nt;
-    const int b = L / a.n_nt;
-    const int t0 = a.t_begin + nt * BN;
+    int L = vqw_xcd_remap(bid, g.nwg);
+    const int mt = L % g.n_mt;
+    L /= g.n_mt;
+    const int nt = L % g.n_nt;
+    const int b = L / g.n_nt;
+    const int t0 = g.t_begin + nt * BN;
     const int o0 = GATE ? mt * (BM / 2) : mt * BM;  // first output row / gated channel
     const int Ctot = d.C0 + d.C1;
     const int kchunks = Ctot / BK;
@@ -596,16 +598,39 @@ __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4))
     }
 }
 
+// The launch: `main` tiles first, then (optionally) the last columns of every row as tiles half as wide, so that
+// the chip's last round is made of small blocks that fill in behind the big ones instead of a thin round of big
+// blocks (B*T = 13*2^12 makes every tiling a multiple of 13 blocks).  ONE LDS array, sized for the main tile
+// (a second __shared__ object beside LDS-DMA traffic makes hipcc drain vmcnt before every ds_read).
+template <int MT, int NT, int EPI>
+__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(16))) float smem[NST * BK * 64 * (MT + NT)];
+    const int bid = blockIdx.x;
+    if (bid < a.main.nwg) {
+        conv_block<MT, NT, EPI>(a, smem, bid, a.main);
+    } else {
+        if constexpr (NT > 1) conv_block<MT, NT / 2, EPI>(a, smem, bid - a.main.nwg, a.tail);
+    }
+}
+
 template <int MT, int NT>
-int launch_cfg(ConvArgs& a, hipStream_t st, int t_begin, int t_cols) {
+int launch_cfg(ConvArgs& a, hipStream_t st, int tail_nt) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     const vqw_conv_desc& d = a.d;
     const bool gate = d.epilogue == VQW_EPI_GATE;
-    a.n_mt = gate ? vqw_cdiv(a.H, BM / 2) : vqw_cdiv(d.M, BM);
-    a.n_nt = vqw_cdiv(t_cols, BN);
-    a.t_begin = t_begin;
-    a.nwg = a.n_mt * a.n_nt * d.B;
-    dim3 grid(a.nwg), block(256);
+    const int n_mt = gate ? vqw_cdiv(a.H, BM / 2) : vqw_cdiv(d.M, BM);
+    const int n_nt = vqw_cdiv(d.T_out, BN);
+    if (NT == 1 || tail_nt <= 0 || tail_nt >= n_nt) tail_nt = 0;
+    a.main = BlockGrid{n_mt, n_nt - tail_nt, n_mt * (n_nt - tail_nt) * d.B, 0};
+    a.tail = BlockGrid{n_mt, 0, 0, 0};
+    if (tail_nt > 0) {
+        const int t_main = (n_nt - tail_nt) * BN;
+        a.tail.n_nt = vqw_cdiv(d.T_out - t_main, BN / 2);
+        a.tail.nwg = n_mt * a.tail.n_nt * d.B;
+        a.tail.t_begin = t_main;
+    }
+    dim3 grid(a.main.nwg + a.tail.nwg), block(256);
     switch (d.epilogue) {
         case VQW_EPI_STORE:
             hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, VQW_EPI_STORE>), grid, block, 0, st, a);
@@ -704,10 +729,10 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
         tile = 10 * mt + ntile;
     }
     // A GEMM whose block count leaves a thin last round (B*T = 13*2^12 makes every tiling a multiple of 13
-    // blocks; measured on the gate conv: two full rounds of 768 blocks, then 128 blocks alone on a mostly idle
-    // chip = 16 % of the kernel) is cut in two launches: whole rounds of the chosen tile over the first columns,
-    // the remaining columns with tiles half as wide, which spread over all CUs.  Explicit form of `tile`:
-    // main + 100*tail_tile + 10000*(main-tile columns given to the tail); VQW_CONV_TAIL=0 disables the auto cut.
+    // blocks; measured on the gate conv: two full rounds of 768 blocks, then 128 blocks on a mostly idle chip)
+    // gives the last columns of every row to tiles half as wide, appended to the same grid: they start as the
+    // big blocks of the last full round retire and spread over all CUs.  Explicit form of `tile`:
+    // main + 10000*(main-tile columns given to the half-width tiles); VQW_CONV_TAIL=0 disables the auto choice.
     static const int tail_env = [] { const char* e = getenv("VQW_CONV_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
     static const int cus = [] {
         int dev = 0, n = 256;
@@ -715,35 +740,23 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
         return n > 0 ? n : 256;
     }();
     const int main_tile = tile % 100;
-    int tail_tile = (tile / 100) % 100, tail_nt = tile / 10000;
+    int tail_nt = tile / 10000;
     const int mtm = main_tile / 10, ntm = main_tile % 10;
     if (mtm < 1 || mtm > 2 || (ntm != 1 && ntm != 2 && ntm != 4)) return vqw_set_error("vqw_conv_gemm: unsupported tile %d", tile);
-    const int BNm = 64 * ntm;
-    const int n_nt = vqw_cdiv(d.T_out, BNm);
-    if (tail_tile == 0 && tail_env && ntm > 1) {
-        const int occ = (main_tile == 22) ? 3 : (main_tile == 24 || main_tile == 14) ? 2 : (main_tile == 11) ? 6 : 4;
+    if (tile < 10000 && tail_env && ntm > 1) {
+        const int occ = (main_tile == 22) ? 3 : (main_tile == 24 || main_tile == 14) ? 2 : 4;
         const int n_mt = (d.epilogue == VQW_EPI_GATE) ? vqw_cdiv(a.H, 32 * mtm) : vqw_cdiv(d.M, 64 * mtm);
-        const long slots = (long)cus * occ, per_col = (long)n_mt * d.B, nblk = per_col * n_nt;
+        const long slots = (long)cus * occ, per_col = (long)n_mt * d.B, nblk = per_col * vqw_cdiv(d.T_out, 64 * ntm);
         const long rem = nblk % slots;
-        if (nblk > slots && rem > 0 && rem * 10 < slots * 7) {
-            tail_nt = (int)((rem + per_col - 1) / per_col);
-            tail_tile = 10 * mtm + ntm / 2;
-        }
+        if (nblk > slots && rem > 0 && rem * 10 < slots * 7) tail_nt = (int)((rem + per_col - 1) / per_col);
     }
-    auto launch = [&](int t, int t_begin, int t_cols) -> int {
-        switch (t) {
-            case 24: return launch_cfg<2, 4>(a, st, t_begin, t_cols);
-            case 22: return launch_cfg<2, 2>(a, st, t_begin, t_cols);
-            case 21: return launch_cfg<2, 1>(a, st, t_begin, t_cols);
-            case 14: return launch_cfg<1, 4>(a, st, t_begin, t_cols);
-            case 12: return launch_cfg<1, 2>(a, st, t_begin, t_cols);
-            case 11: return launch_cfg<1, 1>(a, st, t_begin, t_cols);
-            default: return vqw_set_error("vqw_conv_gemm: unsupported tile %d", t);
-        }
-    };
-    if (tail_tile == 0 || tail_nt <= 0 || tail_nt >= n_nt) return launch(main_tile, 0, d.T_out);
-    const int t_main = (n_nt - tail_nt) * BNm;
-    const int rc = launch(main_tile, 0, t_main);
-    if (rc) return rc;
-    return launch(tail_tile, t_main, d.T_out - t_main);
+    switch (main_tile) {
+        case 24: return launch_cfg<2, 4>(a, st, tail_nt);
+        case 22: return launch_cfg<2, 2>(a, st, tail_nt);
+        case 21: return launch_cfg<2, 1>(a, st, 0);
+        case 14: return launch_cfg<1, 4>(a, st, tail_nt);
+        case 12: return launch_cfg<1, 2>(a, st, tail_nt);
+        case 11: return launch_cfg<1, 1>(a, st, 0);
+        default: return vqw_set_error("vqw_conv_gemm: unsupported tile %d", tile);
+    }
 }

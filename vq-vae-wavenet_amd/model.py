@@ -88,7 +88,7 @@ class VQVAE:
         # per-call-site tile choices of the conv engine (10*MT+NT; 0 = library heuristic), from
         # tools/bench_kernels.py on MI355X at B=8, T=6656: block counts are 13*2^k, so the tile
         # that balances best over 256 CUs differs per GEMM shape
-        self.tiles = {'out': 14, 'gate_bwd': 12, 'dgrad': 12}
+        self.tiles = {'out': 12, 'gate_bwd': 12, 'dgrad': 12}
 
     # ------------------------------------------------------------------ parameter layout
     def _build_layout(self):
