@@ -2,30 +2,36 @@
 // (216 tf.matmul + 91 FIFOQueue ops + numpy sampling per sample in the reference,
 // wavenet.py:103-172 / wavenet_ops.py:147-267 / utils.py:13-46) in ONE launch.
 //
-// Decomposition: R/8 workgroups (one per CU), workgroup bi owns channels 8 bi .. 8 bi + 7 of
-// every matrix of the model (plus the same columns of the wider ones), so a sample is a chain
-// of 2L+3 phases, each = "gather the full input vector, multiply by my columns, publish my
-// outputs".  The exchange follows the R2 recipe of the CDNA guide (Guideline 16): every value
-// travels as ONE naturally aligned 8-byte granule {tag, fp32 bits} written with a relaxed
-// agent-scope atomic store (sc1, write-through) and polled with relaxed agent-scope atomic
-// loads; the tag is a per-phase sequence number, so no flags, fences or resets are needed and
-// nothing depends on dispatch order or XCD placement.  The per-layer exchange buffer of the
-// layer input doubles as the dilation queue (ring of (k-1)d+1 time slots).
+// Decomposition: R/8 workgroups (one per CU), workgroup bi owns channels 8 bi .. 8 bi + 7 of every matrix of
+// the model.  Values cross workgroups by the R2 recipe of the CDNA guide (Guideline 16): ONE naturally aligned
+// 8-byte granule {tag, fp32 bits} per value, written with a relaxed agent-scope atomic store (sc1, write-through)
+// and polled with relaxed agent-scope atomic loads; the tag is a per-phase sequence number, so no flags, fences
+// or resets are needed and nothing depends on dispatch order or XCD placement.  The per-layer exchange buffer of
+// the layer input doubles as the dilation queue (ring of (k-1)d+1 time slots).
 //
-// A workgroup has two roles (measured with tools/ar_trace.py: a wave that polls behind its own
-// weight loads waits for them, vmcnt returns in order -- 6.5 of 8.1 us per layer were weight-load
-// latency in the single-role version):
-//   waves 0-3 "compute": keep the NEXT phase's weight columns in registers (16-byte loads from
-//             a per-thread blocked copy, issued one phase ahead, served by L2 / Infinity
-//             Cache while the exchange is in flight), multiply, reduce over a half wave,
-//             publish.  They never poll global memory.
-//   waves 4-7 "gather":  poll the granules of the phase (all loads of a phase in flight at
-//             once), strip the tags into LDS, meet the compute waves at a raw s_barrier.
-// Head weights (skip0, postprocess1/2, preprocess), all biases and the condition projections
-// of the current frame live in LDS.  Every spin is bounded by a wall-clock timeout
-// (s_memrealtime) that sets an error word and drains the grid.
+// ONE exchange per layer.  The reference layer is  gate_l = act(Wg_l * [cur_l taps] + cond),
+// cur_{l+1} = cur_l + Wr_l gated_l + br_l  (wavenet_ops.py:212-267): two dependent matrix-vector products, i.e.
+// two all-gathers per layer (~1.1 us each, measured with tools/ar_trace.py: the exchange, not the arithmetic, is
+// the price of a sample).  Here the current-tap product is re-associated,
+//     Wg_l^cur cur_l = Wg_l^cur cur_{l-1} + (Wg_l^cur Wr_{l-1}) gated_{l-1} + Wg_l^cur br_{l-1},
+// with M_l = Wg_l^cur Wr_{l-1} and the folded bias formed once per handle in fp64, so phase l needs only the
+// vectors cur_{l-1} and gated_{l-1}, which phase l-1 publishes TOGETHER: phase l = {residual + skip of layer
+// l-1, gate of layer l}.  The residual chain itself keeps the reference's operation order bit for bit; only the
+// gate pre-activation sees the re-association (~1e-7 relative).  A sample is L+1 phases + 3 head exchanges.
+//
+// A workgroup has three roles (a wave that polls behind its own weight loads waits for them, vmcnt returns in
+// order):
+//   waves 0-3 "compute": weight columns in registers, requested one phase ahead (the critical ones -- current
+//             tap, M, residual, skip -- right behind the phase's publishes, the past-tap ones in front of the
+//             barrier) as 16-byte loads from a per-thread blocked copy served by L2 / Infinity Cache; the past
+//             taps' share of the dot products is formed while the exchange is in flight.  They never poll.
+//   waves 4-5 "fresh":   poll the granules of the phase into LDS, meet the compute waves at a raw s_barrier.
+//   waves 6-7 "history": fetch the dilation-queue taps two phases ahead (they are old news).
+// Head weights, all biases and the condition projections of the current frame live in LDS.  Every spin is
+// bounded by a wall-clock timeout (s_memrealtime) that sets an error word and drains the grid.
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "ar_persist.h"
@@ -33,25 +39,24 @@
 namespace {
 
 typedef unsigned long long u64;
-constexpr int PB = 8;        // max batch rows
+constexpr int PB = 4;        // max batch rows of one persistent launch (LDS budget; larger batches: several handles)
 constexpr int PJ = 8;        // max Q / R
 constexpr int CPB = 8;       // channels per workgroup
-constexpr int KSMAX = 4;     // taps of the dilated conv handled by the persistent kernel
-constexpr int NCT = 256;     // compute threads (waves 0-3); gather threads are 256..511
+constexpr int NCT = 256;     // compute threads (waves 0-3)
+constexpr int NGL = 128;     // lanes of the fresh role (waves 4-5) and of the history role (waves 6-7)
 constexpr unsigned long long TIMEOUT_TICKS = 300000000ull;  // 3 s of s_memrealtime (100 MHz)
 
 struct PArgs {
-    int L, ks, R, S, Q, B, nS, nQ, pre_k;
-    int ngq, noq;                 // 16-byte groups per compute thread: gate / out weights of a layer
-    const float* gw;              // [L][nwg][ngq][256][4]   element e = (tap*RL + i)*2 + {filter, gate}
-    const float* ow;              // [L][nwg][noq][256][4]   element e = i*(nS+1) + col (skip cols, residual col)
-    const float* headw;           // [nwg][nhead][256]       post1 | post2 | skip0 | preprocess
+    int L, R, S, Q, B, nQ, pre_k;
+    const float* pw;              // [L+1][nwg][NPW][256][4]  past-tap gate columns of phase p; e = (tap*RL + i)*2 + {f, g}
+    const float* cw;              // [L+1][nwg][NCW][256][4]  critical columns of phase p; e = i*(5+NS) + {Wg_f, Wg_g, M_f, M_g, Wr, Ws..}
+    const float* headw;           // [nwg][nhead][256]        post1 | post2 | preprocess
     const float* bias;            // [nwg][nbias]
     const int* dil;               // [L]
     const int* ring_off;          // [L] granule offset of each layer's ring
     u64* rings;                   // sum_l depth_l * B * R granules: layer inputs == dilation queues
     const float* const* cond;     // [L+1] this run's condition projections ([B][2R][Tz] ..., [B][S][Tz])
-    u64 *ex_g, *ex_s, *ex_h, *ex_l;  // [B][R], [B][S], [B][S], [B][Q]
+    u64 *ex_g, *ex_s, *ex_h, *ex_l;  // [2][B][R] (phase parity), [B][S], [B][S], [B][Q]
     float* xhist;                 // [B][pre_k] encoded input history (state across runs)
     float* prev;                  // [B] last decoded sample
     int* state;                   // [0] = step, [1] = error
@@ -67,22 +72,23 @@ struct PArgs {
 
 // LDS carve (in floats), shared by the host (size) and the device (offsets)
 struct Carve {
-    int xg, xo, hw, bias, condc, xh, misc, tab, total;
-    int n_p1, n_p2, n_s0, n_pre, nhead, nbias, bias_head;
+    int xfresh, xpast, hx1, hx2, hw, bias, condc, xh, misc, tab, total;
+    int n_p1, n_p2, n_pre, nhead, nbias, bias_head, npast;
 };
 __host__ __device__ inline Carve make_carve(int L, int ks, int R, int S, int Q, int B, int nS, int nQ, int pre_k) {
     Carve c;
-    const int RL = R / 32, SL = S / 32;
-    c.n_p1 = SL * nS; c.n_p2 = SL * nQ; c.n_s0 = RL * nS; c.n_pre = (pre_k + 31) / 32;
-    c.nhead = c.n_p1 + c.n_p2 + c.n_s0 + c.n_pre;
-    c.bias_head = L * (nS + 3) * CPB;                    // per layer: gate {filter, gate}, out {skip cols, residual}
-    c.nbias = c.bias_head + (2 * nS + nQ + 1) * CPB;     // skip0, post1, post2, preprocess
-    int nx = ks * B * R;
-    if (B * S > nx) nx = B * S;
-    if (B * Q > nx) nx = B * Q;
-    c.xg = 0;
-    c.xo = c.xg + nx;
-    c.hw = c.xo + B * S;
+    const int SL = S / 32;
+    c.n_p1 = SL * nS; c.n_p2 = SL * nQ; c.n_pre = (pre_k + 31) / 32;
+    c.nhead = c.n_p1 + c.n_p2 + c.n_pre;
+    c.bias_head = (L + 1) * (nS + 3) * CPB;              // per phase: folded gate bias {f, g}, residual bias, skip biases
+    c.nbias = c.bias_head + (nS + nQ + 1) * CPB;         // post1, post2, preprocess
+    c.npast = (ks - 1) * B * R;
+    const int nh = (B * S > B * Q) ? B * S : B * Q;
+    c.xfresh = 0;
+    c.xpast = c.xfresh + 2 * 2 * B * R;
+    c.hx1 = c.xpast + 3 * c.npast;
+    c.hx2 = c.hx1 + nh;
+    c.hw = c.hx2 + B * S;
     c.bias = c.hw + c.nhead * NCT;
     c.condc = c.bias + ((c.nbias + 3) & ~3);
     c.xh = c.condc + (L * 2 + nS) * CPB * B;
@@ -120,7 +126,10 @@ __device__ __forceinline__ u64 poll_granule(int* fail, const u64* p, unsigned ta
     const u64 t_start = __builtin_amdgcn_s_memrealtime();
     u64 g1 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned spins = 1;; ++spins) {
-        __builtin_amdgcn_s_sleep(2);
+#ifndef ARP_SPIN_SLEEP
+#define ARP_SPIN_SLEEP 2
+#endif
+        __builtin_amdgcn_s_sleep(ARP_SPIN_SLEEP);
         const u64 g2 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(g1 >> 32) == tag) return g1;
         g1 = g2;
@@ -132,28 +141,27 @@ __device__ __forceinline__ u64 poll_granule(int* fail, const u64* p, unsigned ta
     }
 }
 
-// Gather lanes: nseg segments of n granules each -> dst[s*n + i].  All first loads of a chunk are
+// Gather lanes (NL of them): nseg segments of n granules each -> dst[s*n + i].  All first loads of a chunk are
 // issued before the first tag is looked at; src[s] == nullptr reads as zeros (zero-filled queues).
-template <int NSEG>
+template <int NSEG, int NL>
 __device__ __forceinline__ void gather_segs(int gid, int* fail, const u64* const* src, const unsigned* tag,
-                                            int nseg, int n, float* dst, int relu) {
+                                            int n, float* dst, int relu) {
     constexpr int CH = 4;
-    for (int base = gid; base < n; base += NCT * CH) {
+    for (int base = gid; base < n; base += NL * CH) {
         u64 v[NSEG][CH];
 #pragma unroll
         for (int s = 0; s < NSEG; ++s)
 #pragma unroll
             for (int m = 0; m < CH; ++m) {
-                const int idx = base + NCT * m;
-                v[s][m] = (s < nseg && src[s] && idx < n)
-                              ? __hip_atomic_load(src[s] + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const int idx = base + NL * m;
+                v[s][m] = (src[s] && idx < n) ? __hip_atomic_load(src[s] + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             }
 #pragma unroll
         for (int s = 0; s < NSEG; ++s)
 #pragma unroll
             for (int m = 0; m < CH; ++m) {
-                const int idx = base + NCT * m;
-                if (s < nseg && idx < n) {
+                const int idx = base + NL * m;
+                if (idx < n) {
                     float x = 0.0f;
                     if (src[s]) x = __uint_as_float((unsigned)poll_granule(fail, src[s] + idx, tag[s], v[s][m]));
                     dst[(size_t)s * n + idx] = relu ? fmaxf(x, 0.0f) : x;
@@ -162,21 +170,23 @@ __device__ __forceinline__ void gather_segs(int gid, int* fail, const u64* const
     }
 }
 
-// Sum over the 32 lanes of a half wave, every lane receives the total: four DPP steps inside each row of
-// 16 (full-rate VALU, no LDS round trip) and one cross-row ds_bpermute.  (Five ds_bpermute round trips
-// per dot product were a third of a phase's compute time.)
-template <int CTRL>
+// Sum over the 32 lanes of a half wave with DPP only (full-rate VALU, no LDS round trip): four steps inside each
+// row of 16, then row_bcast15 adds row 0's total into row 1 (and row 2's into row 3).  The total is valid in
+// lanes 16-31 / 48-63: the publishing lane of a channel is its lane 31.
+template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false));
 }
 __device__ __forceinline__ float half_sum(float v) {
-    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);   // row_half_mirror
-    v = dpp_add<0x140>(v);   // row_mirror
-    v += __shfl_xor(v, 16);
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);   // row_mirror
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
     return v;
 }
+constexpr int PUBL = 31;          // lane (within the half wave) that holds a channel's sums and publishes them
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // softmax + sampling + mu-law decode of the batch rows this wave owns (row b -> wave b): utils.py:13-46,
 // mu_law_ops.py:26-31.  Every workgroup does it redundantly (identical bits everywhere); xh receives
@@ -239,6 +249,9 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
     }
 }
 
+#ifndef ARP_POLL_SLEEP
+#define ARP_POLL_SLEEP 12
+#endif
 #ifdef VQW_AR_TRACE
 #define TR_DECL u64 tr_acc[16] = {0}; u64 tr_t = __builtin_amdgcn_s_memrealtime();
 #define TR(i) { const u64 n_ = __builtin_amdgcn_s_memrealtime(); tr_acc[i] += n_ - tr_t; tr_t = n_; }
@@ -250,31 +263,32 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
 #endif
 
 // TB: compile-time bound of the batch rows; RLT = R/32 rows of a weight column per lane; NS = S/R; KS taps.
-// (Compile-time load counts let the compiler wait with exact vmcnt values: with a run-time count it fell back
-// to vmcnt(0) in front of the out phase, i.e. waited for the gate weights it had requested a moment earlier.)
+// (Compile-time load counts let the compiler wait with exact vmcnt values: with a run-time count it falls back to
+// vmcnt(0) in front of the first use, i.e. waits for the loads it has requested a moment earlier.)
 template <int TB, int RLT, int NS, int KS>
 __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
     extern __shared__ float lds[];
-    constexpr int SL = RLT * NS;                       // S / 32
-    constexpr int NGQ = (KS * RLT * 2 + 3) / 4;        // float4 groups of gate weights per thread
-    constexpr int NOQ = (RLT * (NS + 1) + 3) / 4;      // float4 groups of out weights per thread
+    constexpr int SL = RLT * NS;                          // S / 32
+    constexpr int NCOL = 5 + NS;                          // critical columns per weight row: Wg f,g | M f,g | Wr | Ws..
+    constexpr int NPW = ((KS - 1) * RLT * 2 + 3) / 4;     // float4 groups per thread: past taps
+    constexpr int NCW = (RLT * NCOL + 3) / 4;             // float4 groups per thread: critical columns
     const int bi = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
-    const bool compute = tid < NCT;
-    const int ct = tid & (NCT - 1);                    // index inside the role
+    const int role = tid >> 8 ? (tid >> 7) - 1 : 0;       // 0 compute (tid < 256), 1 fresh (256..383), 2 history (384..511)
+    const int ct = tid & (NCT - 1);
     const int cg = ct >> 5, kl = ct & 31;
-    const int c = bi * CPB + cg;                       // compute thread's channel
-    constexpr int ks = KS;
+    const int c = bi * CPB + cg;                          // compute thread's channel
     const int B = a.B, R = a.R, S = a.S, Q = a.Q, L = a.L, nQ = a.nQ;
-    const Carve cv = make_carve(L, ks, R, S, Q, B, NS, nQ, a.pre_k);
-    float* const xg = lds + cv.xg;                     // gate inputs [ks][B][R] / head inputs [B][S] / logits [B][Q]
-    float* const xo = lds + cv.xo;                     // out inputs [B][R] / postprocess2 inputs [B][S]
+    const Carve cv = make_carve(L, KS, R, S, Q, B, NS, nQ, a.pre_k);
+    float* const xfresh = lds + cv.xfresh;                // [2][{cur_{p-1}, gated_{p-1}}][B][R]
+    float* const xpast = lds + cv.xpast;                  // [3][KS-1][B][R]
+    float* const hx1 = lds + cv.hx1;                      // relu(skip) [B][S], later the logits [B][Q]
+    float* const hx2 = lds + cv.hx2;                      // relu(h) [B][S]
     const float* const hw_p1 = lds + cv.hw;
     const float* const hw_p2 = hw_p1 + cv.n_p1 * NCT;
-    const float* const hw_s0 = hw_p2 + cv.n_p2 * NCT;
-    const float* const hw_pre = hw_s0 + cv.n_s0 * NCT;
+    const float* const hw_pre = hw_p2 + cv.n_p2 * NCT;
     const float* const bs = lds + cv.bias;
-    float* const condc = lds + cv.condc;               // [L][2][8][B], then postprocess1 [NS][8][B]
-    float* const xh = lds + cv.xh;                     // [B][pre_k]
+    float* const condc = lds + cv.condc;                  // [L][2][8][B], then postprocess1 [NS][8][B]
+    float* const xh = lds + cv.xh;                        // [B][pre_k]
     float* const misc = lds + cv.misc;
     int* const fail = reinterpret_cast<int*>(misc + 60);
     int* const tab = reinterpret_cast<int*>(lds + cv.tab);   // [L] dilation, [L] ring offset
@@ -290,25 +304,25 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
     if (tid < B) xh[tid * a.pre_k + (t0 % a.pre_k)] = p_mu_enc(a.prev[tid]);   // x_in(t0) = mu_law_encode(previous sample)
     __syncthreads();
 
-    const int PH = 2 * L + 4;
-    const size_t nBR = (size_t)B * R;
+    const int PH = L + 4;                                 // tags of a step: gated_p (p < L), skip, h, logits
+    const int nBR = B * R;
     TR_DECL
 
-    if (compute) {
+    if (role == 0) {
         // ======================================================================== compute waves
-        f32x4 gq[NGQ], oq[NOQ];
-        auto load_gate = [&](int l) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.gw) + ((size_t)(l * nwg + bi) * NGQ) * NCT + ct;
+        f32x4 pw[NPW], cw[NCW];
+        auto load_pw = [&](int p) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(a.pw) + ((size_t)(p * nwg + bi) * NPW) * NCT + ct;
 #pragma unroll
-            for (int q = 0; q < NGQ; ++q) gq[q] = p[(size_t)q * NCT];
+            for (int i = 0; i < NPW; ++i) pw[i] = q[(size_t)i * NCT];
         };
-        auto load_out = [&](int l) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.ow) + ((size_t)(l * nwg + bi) * NOQ) * NCT + ct;
+        auto load_cw = [&](int p) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(a.cw) + ((size_t)(p * nwg + bi) * NCW) * NCT + ct;
 #pragma unroll
-            for (int q = 0; q < NOQ; ++q) oq[q] = p[(size_t)q * NCT];
+            for (int i = 0; i < NCW; ++i) cw[i] = q[(size_t)i * NCT];
         };
-        load_gate(0);
-        load_out(0);
+        load_pw(0);
+        load_cw(0);
         float cur[TB], skipacc[NS][TB];
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
@@ -316,14 +330,17 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) skipacc[j][b] = 0.0f;
         }
-
-        for (int it = 0; it < a.n_steps; ++it) {
+        role_barrier();                                    // BAR_INIT: the history waves' prologue is in LDS
+        __builtin_amdgcn_s_setprio(3);                     // the pollers sharing my SIMD never delay the critical chain
+        int p = 0, it = 0, P = 0;
+        bool stop = false;
+        auto phase = [&]() {
             const int t = t0 + it;
             const unsigned seq = (unsigned)t * (unsigned)PH + 1u;
             const unsigned ttag = (unsigned)t + 1u;
-            // ---------------- preprocess: causal conv over the encoded input history, lane kl = tap kl (+32)
-            {
-                const int depth0 = (ks - 1) * tab[0] + 1;
+            if (p == 0) {
+                // ---------------- preprocess: causal conv over the encoded input history, lane kl = tap kl (+32)
+                const int depth0 = (KS - 1) * tab[0] + 1;
                 u64* ring0 = a.rings + tab[L] + (size_t)(t % depth0) * nBR;
 #pragma unroll
                 for (int b = 0; b < TB; ++b) {
@@ -337,232 +354,283 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                                 acc = fmaf(hw_pre[i * NCT + ct], xh[b * a.pre_k + slot], acc);
                             }
                         }
-                        cur[b] = half_sum(acc) + bs[cv.bias_head + (2 * NS + nQ) * CPB + cg];
-                        if (kl == 0) publish(ring0 + (size_t)b * R + c, ttag, cur[b]);
+                        cur[b] = half_sum(acc) + bs[cv.bias_head + (NS + nQ) * CPB + cg];
+                        if (kl == PUBL) publish(ring0 + (size_t)b * R + c, ttag, cur[b]);
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) skipacc[j][b] = 0.0f;
                     }
                 }
             }
             TR(0)
-            for (int l = 0; l < L; ++l) {
-                const float* bl = bs + l * (NS + 3) * CPB;
-                // the taps t-(ks-1)d .. t-d are old news: their share of the dot products is done while the
-                // current layer input is still travelling
-                float af[TB], ag[TB];
-                role_barrier();                                    // BAR0: xg[0..ks-2] = cur_l(t - (ks-1-j) d)
-                TR(1)
+            // ---------------- the old taps' share of the gate pre-activation (while the exchange is in flight)
+            float pf[TB], pg[TB];
+            {
+                const float* xp = xpast + (P % 3) * cv.npast;
 #pragma unroll
                 for (int b = 0; b < TB; ++b) {
-                    af[b] = 0.0f; ag[b] = 0.0f;
-                    if (b < B) {
+                    pf[b] = 0.0f; pg[b] = 0.0f;
+                    if (b < B && p < L) {
 #pragma unroll
                         for (int j = 0; j < KS - 1; ++j) {
 #pragma unroll
                             for (int i = 0; i < RLT; ++i) {
-                                const float xv = xg[((size_t)j * B + b) * R + kl + 32 * i];
+                                const float xv = xp[(j * B + b) * R + kl + 32 * i];
                                 const int e = (j * RLT + i) * 2;
-                                af[b] = fmaf(gq[e >> 2][e & 3], xv, af[b]);
-                                ag[b] = fmaf(gq[(e + 1) >> 2][(e + 1) & 3], xv, ag[b]);
+                                pf[b] = fmaf(pw[e >> 2][e & 3], xv, pf[b]);
+                                pg[b] = fmaf(pw[(e + 1) >> 2][(e + 1) & 3], xv, pg[b]);
                             }
                         }
                         if (TB > 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                TR(12)
-                role_barrier();                                    // BAR1: xg[ks-1] = cur_l(t)
-                TR(13)
-#pragma unroll
-                for (int b = 0; b < TB; ++b) {
-                    if (b < B) {
-                        const float* xc = xg + ((size_t)(KS - 1) * B + b) * R;
-                        float f = af[b], g = ag[b];
-#pragma unroll
-                        for (int i = 0; i < RLT; ++i) {
-                            const float xv = xc[kl + 32 * i];
-                            const int e = ((KS - 1) * RLT + i) * 2;
-                            f = fmaf(gq[e >> 2][e & 3], xv, f);
-                            g = fmaf(gq[(e + 1) >> 2][(e + 1) & 3], xv, g);
-                        }
-                        f = half_sum(f);
-                        g = half_sum(g);
-                        if (l == 0) {   // skip = linear(current)  (wavenet.py:127-128)
-#pragma unroll
-                            for (int j = 0; j < NS; ++j) {
-                                float s0 = 0.0f;
-#pragma unroll
-                                for (int i = 0; i < RLT; ++i) s0 = fmaf(hw_s0[(i * NS + j) * NCT + ct], xc[kl + 32 * i], s0);
-                                skipacc[j][b] = half_sum(s0) + bs[cv.bias_head + j * CPB + cg];
-                            }
-                        }
-                        if (kl == 0) {
-                            const float vf = f + bl[cg] + condc[((l * 2 + 0) * CPB + cg) * B + b];
-                            const float vg = g + bl[CPB + cg] + condc[((l * 2 + 1) * CPB + cg) * B + b];
-                            const float th = 1.0f - 2.0f / (__expf(2.0f * vf) + 1.0f);
-                            const float sg = 1.0f / (1.0f + __expf(-vg));
-                            publish(a.ex_g + (size_t)b * R + c, seq + 2 * l, th * sg);
-                        }
-                        if (TB > 1) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                TR(14)
-                load_gate(l + 1 < L ? l + 1 : 0);                  // next gate phase's columns: a whole layer to land
-                TR(2)
-                role_barrier();                                    // BAR2: xo = gated_l(t)
-                TR(3)
-                // ---------------- out phase: skip columns (private accumulators) + residual column
-#pragma unroll
-                for (int b = 0; b < TB; ++b) {
-                    if (b < B) {
-#pragma unroll
-                        for (int j = 0; j <= NS; ++j) {
-                            float s = 0.0f;
-#pragma unroll
-                            for (int i = 0; i < RLT; ++i) {
-                                const int e = i * (NS + 1) + j;
-                                s = fmaf(oq[e >> 2][e & 3], xo[(size_t)b * R + kl + 32 * i], s);
-                            }
-                            s = half_sum(s) + bl[(2 + j) * CPB + cg];
-                            if (j < NS) skipacc[j < NS ? j : 0][b] += s;
-                            else cur[b] += s;
-                        }
-                        if (l + 1 < L && kl == 0) {
-                            const int depth = (ks - 1) * tab[l + 1] + 1;
-                            publish(a.rings + tab[L + l + 1] + ((size_t)(t % depth) * B + b) * R + c, ttag, cur[b]);
-                        }
-                        if (TB > 1) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if (l + 1 == L && kl == 0) {   // postprocess1 input
-#pragma unroll
-                    for (int b = 0; b < TB; ++b)
-#pragma unroll
-                        for (int j = 0; j < NS; ++j)
-                            if (b < B) publish(a.ex_s + (size_t)b * S + c + (size_t)j * R, seq + 2 * L, skipacc[j][b]);
-                }
-                load_out(l + 1 < L ? l + 1 : 0);
-                TR(4)
             }
-            // ---------------- postprocess1: relu(skip) -> 1x1 + condition  (wavenet.py:152-162)
-            role_barrier();                                        // BAR3: xg = relu(skip) [B][S]
-            TR(5)
+            __builtin_amdgcn_sched_barrier(0);
+            load_pw(p + 1 > L ? 0 : p + 1);                // a whole phase to land
+            __builtin_amdgcn_sched_barrier(0);
+            const float* bl = bs + p * (NS + 3) * CPB;
+            float cf[TB], cgv[TB];                         // bias + condition of my channel's filter / gate row
+            u64* ringp = nullptr;                          // where cur_p(t) of my channel goes
+            auto cond_bias = [&]() {
+#pragma unroll
+                for (int b = 0; b < TB; ++b) {
+                    const int bb = (b < B) ? b : 0;
+                    cf[b] = bl[cg] + condc[((p * 2 + 0) * CPB + cg) * B + bb];
+                    cgv[b] = bl[CPB + cg] + condc[((p * 2 + 1) * CPB + cg) * B + bb];
+                }
+            };
+#pragma unroll
+            for (int b = 0; b < TB; ++b) { cf[b] = 0.0f; cgv[b] = 0.0f; }
+            if (p < L) {
+                if (p > 0) cond_bias();                    // (phase 0 reads them behind the barrier: the fresh waves may be
+                const int depth = (KS - 1) * tab[p] + 1;   //  loading a new frame's projections right now)
+                ringp = a.rings + tab[L + p] + (size_t)(t % depth) * nBR + c;
+            }
+            const float brv = bl[2 * CPB + cg];
+            u64* const exgp = a.ex_g + (size_t)(P & 1) * nBR + c;
+            TR(1)
+            role_barrier();                                // BAR_A: xfresh[P&1] = {cur_{p-1}(t), gated_{p-1}(t)}
+            TR(2)
+            const float* vA = xfresh + (P & 1) * 2 * nBR;
+            const float* vB = (p == 0) ? vA : vA + nBR;    // phase 0: skip = linear(cur_0) rides in the Ws slot
+            if (p == 0) cond_bias();
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
                 if (b < B) {
+                    float f = pf[b], g = pg[b], r = 0.0f, sk[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) sk[j] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < RLT; ++i) {
+                        const float xa = vA[b * R + kl + 32 * i], xv = vB[b * R + kl + 32 * i];
+                        const int e = i * NCOL;
+                        f = fmaf(cw[e >> 2][e & 3], xa, f);
+                        g = fmaf(cw[(e + 1) >> 2][(e + 1) & 3], xa, g);
+                        f = fmaf(cw[(e + 2) >> 2][(e + 2) & 3], xv, f);
+                        g = fmaf(cw[(e + 3) >> 2][(e + 3) & 3], xv, g);
+                        r = fmaf(cw[(e + 4) >> 2][(e + 4) & 3], xv, r);
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) sk[j] = fmaf(cw[(e + 5 + j) >> 2][(e + 5 + j) & 3], xv, sk[j]);
+                    }
+                    f = half_sum(f);
+                    g = half_sum(g);
+                    r = half_sum(r);
+                    cur[b] += r + brv;                     // net = net + (residual conv + bias)  (wavenet_ops.py:266)
+                    if (kl == PUBL && p < L) {
+                        const float vf = f + cf[b];
+                        const float vg = g + cgv[b];
+                        const float th = 1.0f - 2.0f * fast_rcp(__expf(2.0f * vf) + 1.0f);   // v_rcp_f32: 1 ulp
+                        const float sg = fast_rcp(1.0f + __expf(-vg));
+                        publish(exgp + (size_t)b * R, seq + p, th * sg);
+                        if (p > 0) publish(ringp + (size_t)b * R, ttag, cur[b]);
+                    }
 #pragma unroll
                     for (int j = 0; j < NS; ++j) {
-                        float s = 0.0f;
+                        skipacc[j][b] += half_sum(sk[j]) + bl[(3 + j) * CPB + cg];   // skip = skip + (skip conv + bias)
+                        if (p == L && kl == PUBL) publish(a.ex_s + (size_t)b * S + c + (size_t)j * R, seq + L, skipacc[j][b]);
+                    }
+                    if (TB > 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            TR(3)
+            __builtin_amdgcn_sched_barrier(0);             // publishes first: hipcc otherwise hoists the independent loads above them
+#ifdef ARP_CW_SLEEP
+            __builtin_amdgcn_s_sleep(ARP_CW_SLEEP);
+#endif
+            load_cw(p + 1 > L ? 0 : p + 1);                // the exchange's travel time to land
+            __builtin_amdgcn_sched_barrier(0);
+            TR(4)
+            if (p == L) {
+                // ---------------- postprocess1: relu(skip) -> 1x1 + condition  (wavenet.py:152-162)
+                role_barrier();                            // BAR_H1: hx1 = relu(skip) [B][S]
+                TR(5)
 #pragma unroll
-                        for (int i = 0; i < SL; ++i) s = fmaf(hw_p1[(i * NS + j) * NCT + ct], xg[(size_t)b * S + kl + 32 * i], s);
-                        s = half_sum(s);
-                        if (kl == 0) {
-                            const float v = s + bs[cv.bias_head + (NS + j) * CPB + cg] + condc[((L * 2 + j) * CPB + cg) * B + b];
-                            publish(a.ex_h + (size_t)b * S + c + (size_t)j * R, seq + 2 * L + 1, v);
+                for (int b = 0; b < TB; ++b) {
+                    if (b < B) {
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) {
+                            float s = 0.0f;
+#pragma unroll
+                            for (int i = 0; i < SL; ++i) s = fmaf(hw_p1[(i * NS + j) * NCT + ct], hx1[b * S + kl + 32 * i], s);
+                            s = half_sum(s);
+                            if (kl == PUBL) {
+                                const float v = s + bs[cv.bias_head + j * CPB + cg] + condc[((L * 2 + j) * CPB + cg) * B + b];
+                                publish(a.ex_h + (size_t)b * S + c + (size_t)j * R, seq + L + 1, v);
+                            }
                         }
                     }
                 }
-            }
-            TR(6)
-            // ---------------- postprocess2: relu(h) -> logits  (wavenet.py:165-167)
-            role_barrier();                                        // BAR4: xo = relu(h) [B][S]
-            TR(7)
+                TR(6)
+                // ---------------- postprocess2: relu(h) -> logits  (wavenet.py:165-167)
+                role_barrier();                            // BAR_H2: hx2 = relu(h) [B][S]
+                TR(7)
 #pragma unroll
-            for (int b = 0; b < TB; ++b) {
-                if (b < B) {
-                    for (int j = 0; j < nQ; ++j) {
-                        float s = 0.0f;
+                for (int b = 0; b < TB; ++b) {
+                    if (b < B) {
+                        for (int j = 0; j < nQ; ++j) {
+                            float s = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < SL; ++i) s = fmaf(hw_p2[(i * nQ + j) * NCT + ct], xo[(size_t)b * S + kl + 32 * i], s);
-                        s = half_sum(s);
-                        if (kl == 0) publish(a.ex_l + (size_t)b * Q + c + (size_t)j * R, seq + 2 * L + 2, s + bs[cv.bias_head + (2 * NS + j) * CPB + cg]);
+                            for (int i = 0; i < SL; ++i) s = fmaf(hw_p2[(i * nQ + j) * NCT + ct], hx2[b * S + kl + 32 * i], s);
+                            s = half_sum(s);
+                            if (kl == PUBL) publish(a.ex_l + (size_t)b * Q + c + (size_t)j * R, seq + L + 2, s + bs[cv.bias_head + (NS + j) * CPB + cg]);
+                        }
                     }
                 }
+                TR(8)
+                role_barrier();                            // BAR_H3: hx1 = logits [B][Q]
+                TR(9)
+                decode_rows(a, bi, tid, t, it, hx1, xh);
+                TR(10)
+                if (*reinterpret_cast<volatile int*>(fail)) stop = true;   // stable between BAR_H3 and BAR_H4: nobody polls there
+                role_barrier();                            // BAR_H4: xh holds x_in(t+1)
+                TR(11)
             }
-            TR(8)
-            role_barrier();                                        // BAR5: xg = logits [B][Q]
-            TR(9)
-            decode_rows(a, bi, tid, t, it, xg, xh);
-            TR(10)
-            if (*reinterpret_cast<volatile int*>(fail)) break;     // stable between BAR5 and BAR6: nobody polls there
-            role_barrier();                                        // BAR6: xh holds x_in(t+1)
-            TR(11)
-        }
+            ++P;
+            if (++p > L) { p = 0; ++it; }
+        };
+        while (it < a.n_steps && !stop) phase();
     } else {
         // ======================================================================== gather waves
-        const int gid = ct;
-        int last_frame = -1;
-        for (int it = 0; it < a.n_steps; ++it) {
+        const int gid = tid & (NGL - 1);
+        // History role: the dilation-queue taps of global phase Pq (old news, but ~1.2 us of load latency each) are
+        // requested in one phase and committed to xpast[Pq % 3] in the next one, so that the loads are in flight
+        // across the phase barrier instead of holding it up (a raw s_barrier does not drain vmcnt).
+        constexpr int HMAX = PB * 256 / NGL;               // granules per lane and tap (B <= PB, R <= 256)
+        u64 hv[KS - 1][HMAX];
+        const u64* hsrc[KS - 1];
+        unsigned htag[KS - 1];
+        int hP = -1;
+        auto hist_issue = [&](int Pq) {
+            hP = -1;
+            const int itq = Pq / (L + 1), q = Pq - itq * (L + 1);
+            if (itq >= a.n_steps || q >= L) return;
+            hP = Pq;
+            const int t = t0 + itq;
+            const int dil = tab[q], depth = (KS - 1) * dil + 1;
+            const u64* ring = a.rings + tab[L + q];
+#pragma unroll
+            for (int j = 0; j < KS - 1; ++j) {
+                const int tau = t - (KS - 1 - j) * dil;
+                hsrc[j] = (tau >= 0) ? ring + (size_t)(tau % depth) * nBR : nullptr;
+                htag[j] = (unsigned)tau + 1u;
+#pragma unroll
+                for (int m = 0; m < HMAX; ++m) {
+                    const int idx = gid + NGL * m;
+                    hv[j][m] = (hsrc[j] && idx < nBR) ? __hip_atomic_load(hsrc[j] + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+            }
+        };
+        auto hist_commit = [&]() {
+            if (hP < 0) return;
+            float* dst = xpast + (hP % 3) * cv.npast;
+#pragma unroll
+            for (int j = 0; j < KS - 1; ++j)
+#pragma unroll
+                for (int m = 0; m < HMAX; ++m) {
+                    const int idx = gid + NGL * m;
+                    if (idx < nBR) {
+                        float x = 0.0f;
+                        if (hsrc[j]) x = __uint_as_float((unsigned)poll_granule(fail, hsrc[j] + idx, htag[j], hv[j][m]));
+                        dst[(size_t)j * nBR + idx] = x;
+                    }
+                }
+            hP = -1;
+        };
+        if (role == 2) {
+            hist_issue(0); hist_commit();
+            hist_issue(1); hist_commit();
+            hist_issue(2);                                 // committed in phase 0, read by the compute waves in phase 1..2
+        }
+        role_barrier();                                    // BAR_INIT
+        int p = 0, it = 0, P = 0, last_frame = -1;
+        bool stop = false;
+        while (it < a.n_steps && !stop) {
             const int t = t0 + it;
             const unsigned seq = (unsigned)t * (unsigned)PH + 1u;
-            int frame = t / a.ratio;
-            if (frame >= a.Tz) frame = a.Tz - 1;
-            if (frame != last_frame) {   // condition projections of this frame for my 8 channels (all layers)
-                last_frame = frame;
-                const int per = CPB * B;
-                for (int i = gid; i < (L * 2 + NS) * per; i += NCT) {
-                    const int b = i % B, g8 = (i / B) % CPB, lh = i / per;
-                    const int ch = bi * CPB + g8;
-                    float v;
-                    if (lh < 2 * L) v = a.cond[lh >> 1][((size_t)b * 2 * R + ch + (size_t)(lh & 1) * R) * a.Tz + frame];
-                    else v = a.cond[L][((size_t)b * S + ch + (size_t)(lh - 2 * L) * R) * a.Tz + frame];
-                    condc[i] = v;
-                }
-            }
-            TR(0)
-            for (int l = 0; l < L; ++l) {
-                {   // the ks taps of the layer input: the old ones first (nothing to wait for), then the fresh one
-                    const int dil = tab[l], depth = (ks - 1) * dil + 1;
-                    const u64* ring = a.rings + tab[L + l];
-                    const u64* src[KS];
-                    unsigned tag[KS];
-#pragma unroll
-                    for (int j = 0; j < KS; ++j) {
-                        const int tau = t - (ks - 1 - j) * dil;
-                        src[j] = (tau >= 0) ? ring + (size_t)(tau % depth) * nBR : nullptr;
-                        tag[j] = (unsigned)tau + 1u;
+            const unsigned ttag = (unsigned)t + 1u;
+            if (role == 1) {
+                if (p == 0) {
+                    int frame = t / a.ratio;
+                    if (frame >= a.Tz) frame = a.Tz - 1;
+                    if (frame != last_frame) {   // condition projections of this frame for my 8 channels (all layers)
+                        last_frame = frame;
+                        const int per = CPB * B;
+                        for (int i = gid; i < (L * 2 + NS) * per; i += NGL) {
+                            const int b = i % B, g8 = (i / B) % CPB, lh = i / per;
+                            const int ch = bi * CPB + g8;
+                            float v;
+                            if (lh < 2 * L) v = a.cond[lh >> 1][((size_t)b * 2 * R + ch + (size_t)(lh & 1) * R) * a.Tz + frame];
+                            else v = a.cond[L][((size_t)b * S + ch + (size_t)(lh - 2 * L) * R) * a.Tz + frame];
+                            condc[i] = v;
+                        }
                     }
-                    gather_segs<KS - 1>(gid, fail, src, tag, KS - 1, (int)nBR, xg, 0);
-                    TR(10)
-                    role_barrier();                                // BAR0
-                    TR(11)
-                    gather_segs<1>(gid, fail, src + (KS - 1), tag + (KS - 1), 1, (int)nBR, xg + (size_t)(KS - 1) * nBR, 0);
                 }
+                TR(0)
+                // the input vectors of phase p: cur_{p-1}(t) from its dilation queue (phase 0: cur_0), gated_{p-1}(t)
+                const int lq = (p == 0) ? 0 : p - 1;
+                const int depth = (KS - 1) * tab[lq] + 1;
+                const u64* src[2] = {a.rings + tab[L + lq] + (size_t)(t % depth) * nBR, a.ex_g + (size_t)((P + 1) & 1) * nBR};
+                const unsigned tag[2] = {ttag, seq + (unsigned)lq};
+                // nothing can arrive before the producers' critical chain + the store's travel time: polling earlier only
+                // queues requests in front of the compute waves' weight loads (measured: 84 -> 75 us per sample; 8..20 are equivalent, 1 and 28+ slower)
+                __builtin_amdgcn_s_sleep(ARP_POLL_SLEEP);
+                if (p == 0) gather_segs<1, NGL>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0);
+                else gather_segs<2, NGL>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0);
                 TR(1)
-                role_barrier();                                    // BAR1
-                TR(2)
-                {
-                    const u64* src[1] = {a.ex_g};
-                    const unsigned tag[1] = {seq + 2 * l};
-                    gather_segs<1>(gid, fail, src, tag, 1, (int)nBR, xo, 0);
+            } else {
+                hist_commit();                             // target P+2, requested one phase ago
+                hist_issue(P + 3);
+            }
+            role_barrier();                                // BAR_A
+            TR(2)
+            if (p == L) {
+                if (role == 1) {
+                    const u64* src[1] = {a.ex_s};
+                    const unsigned tag[1] = {seq + (unsigned)L};
+                    gather_segs<1, NGL>(gid, fail, src, tag, B * S, hx1, 1);
                 }
                 TR(3)
-                role_barrier();                                    // BAR2
+                role_barrier();                            // BAR_H1
+                if (role == 1) {
+                    const u64* src[1] = {a.ex_h};
+                    const unsigned tag[1] = {seq + (unsigned)L + 1u};
+                    gather_segs<1, NGL>(gid, fail, src, tag, B * S, hx2, 1);
+                }
                 TR(4)
+                role_barrier();                            // BAR_H2
+                if (role == 1) {
+                    const u64* src[1] = {a.ex_l};
+                    const unsigned tag[1] = {seq + (unsigned)L + 2u};
+                    gather_segs<1, NGL>(gid, fail, src, tag, B * Q, hx1, 0);
+                }
+                TR(5)
+                role_barrier();                            // BAR_H3
+                decode_rows(a, bi, tid, t, it, hx1, xh);
+                if (*reinterpret_cast<volatile int*>(fail)) stop = true;
+                role_barrier();                            // BAR_H4
+                TR(6)
             }
-            {
-                const u64* src[1] = {a.ex_s};
-                const unsigned tag[1] = {seq + 2 * L};
-                gather_segs<1>(gid, fail, src, tag, 1, B * S, xg, 1);
-            }
-            TR(5)
-            role_barrier();                                        // BAR3
-            {
-                const u64* src[1] = {a.ex_h};
-                const unsigned tag[1] = {seq + 2 * L + 1};
-                gather_segs<1>(gid, fail, src, tag, 1, B * S, xo, 1);
-            }
-            TR(6)
-            role_barrier();                                        // BAR4
-            {
-                const u64* src[1] = {a.ex_l};
-                const unsigned tag[1] = {seq + 2 * L + 2};
-                gather_segs<1>(gid, fail, src, tag, 1, B * Q, xg, 0);
-            }
-            TR(7)
-            role_barrier();                                        // BAR5
-            decode_rows(a, bi, tid, t, it, xg, xh);
-            TR(8)
-            if (*reinterpret_cast<volatile int*>(fail)) break;
-            role_barrier();                                        // BAR6
-            TR(9)
+            ++P;
+            if (++p > L) { p = 0; ++it; }
         }
     }
     TR_DUMP
@@ -579,30 +647,85 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// one-time re-blocking of the model's variables: every compute thread's share becomes contiguous
+// one-time re-blocking of the model's variables: every compute thread's share becomes contiguous.
+// Phase p in 0..L: gate of layer p (p < L), residual + skip of layer p-1 (p > 0; phase 0: skip = linear(cur_0)).
 
-// gate kernel [ks][R][2R] of one layer -> dst[bi][q][ct][4]; element e = q*4+r = (tap*RL + i)*2 + h
-__global__ void pack_gate_kernel(const float* __restrict__ src, int ks, int R, int ngq, float* __restrict__ dst) {
+// past-tap gate columns: dst[bi][q][ct][4]; element e = q*4+r = (tap*RL + i)*2 + h, taps 0..ks-2
+__global__ void pack_pw_kernel(const float* __restrict__ gw, int ks, int R, int npw, float* __restrict__ dst) {
     const int RL = R / 32, nwg = R / CPB;
-    const size_t n = (size_t)nwg * ngq * NCT * 4;
+    const size_t n = (size_t)nwg * npw * NCT * 4;
     for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(x & 3), ct = (int)((x >> 2) % NCT), q = (int)((x / (4 * NCT)) % ngq), bi = (int)(x / ((size_t)4 * NCT * ngq));
+        const int r = (int)(x & 3), ct = (int)((x >> 2) % NCT), q = (int)((x / (4 * NCT)) % npw), bi = (int)(x / ((size_t)4 * NCT * npw));
         const int e = q * 4 + r, h = e & 1, i = (e >> 1) % RL, j = (e >> 1) / RL;
         const int c = bi * CPB + (ct >> 5), k = (ct & 31) + 32 * i;
-        dst[x] = (j < ks) ? src[((size_t)j * R + k) * 2 * R + c + h * R] : 0.0f;
+        dst[x] = (gw && j < ks - 1) ? gw[((size_t)j * R + k) * 2 * R + c + h * R] : 0.0f;
     }
 }
 
-// out kernel [R][ld] (skip | residual side by side) of one layer -> dst[bi][q][ct][4]; e = i*(nS+1) + j,
-// column c + j*R for the skip columns j < nS, column S + c for the residual (j == nS)
-__global__ void pack_out_kernel(const float* __restrict__ src, int ld, int R, int S, int nS, int noq, float* __restrict__ dst) {
-    const int RL = R / 32, nwg = R / CPB;
-    const size_t n = (size_t)nwg * noq * NCT * 4;
+// critical columns: dst[bi][q][ct][4]; e = i*(5+nS) + col, weight row k = kl + 32 i:
+//   col 0,1: Wg^cur[k][c + h R]                      (gw: gate kernel [ks][R][2R] of layer p, or null)
+//   col 2,3: M[k][c + h R] = sum_m Wr[k][m] Wg^cur[m][c + h R]   (fp64 accumulation; needs gw and ow)
+//   col 4:   Wr[k][c] = ow[k][S + c]                 (ow: [R][ld] skip | residual of layer p-1, or null)
+//   col 5+j: Ws[k][c + j R] = ow[k][c + j R]         (phase 0: sw = decoder/skip kernel [R][S], ld = S)
+__global__ void pack_cw_kernel(const float* __restrict__ gw, const float* __restrict__ ow, const float* __restrict__ sw,
+                               int ld, int ks, int R, int S, int nS, int ncw, float* __restrict__ dst) {
+    const int RL = R / 32, nwg = R / CPB, ncol = 5 + nS;
+    const size_t n = (size_t)nwg * ncw * NCT * 4;
     for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(x & 3), ct = (int)((x >> 2) % NCT), q = (int)((x / (4 * NCT)) % noq), bi = (int)(x / ((size_t)4 * NCT * noq));
-        const int e = q * 4 + r, i = e / (nS + 1), j = e % (nS + 1);
+        const int r = (int)(x & 3), ct = (int)((x >> 2) % NCT), q = (int)((x / (4 * NCT)) % ncw), bi = (int)(x / ((size_t)4 * NCT * ncw));
+        const int e = q * 4 + r, i = e / ncol, col = e % ncol;
         const int c = bi * CPB + (ct >> 5), k = (ct & 31) + 32 * i;
-        dst[x] = (i < RL) ? src[(size_t)k * ld + (j < nS ? c + j * R : S + c)] : 0.0f;
+        float v = 0.0f;
+        if (i < RL) {
+            const float* gc = gw ? gw + (size_t)(ks - 1) * R * 2 * R : nullptr;   // current tap [R][2R]
+            if (col < 2) {
+                if (gc) v = gc[(size_t)k * 2 * R + c + col * R];
+            } else if (col < 4) {
+                if (gc && ow) {
+                    double acc = 0.0;
+                    for (int m = 0; m < R; ++m) acc += (double)ow[(size_t)k * ld + S + m] * (double)gc[(size_t)m * 2 * R + c + (col - 2) * R];
+                    v = (float)acc;
+                }
+            } else if (col == 4) {
+                if (ow) v = ow[(size_t)k * ld + S + c];
+            } else {
+                const int j = col - 5;
+                if (ow) v = ow[(size_t)k * ld + c + j * R];
+                else if (sw) v = sw[(size_t)k * S + c + j * R];
+            }
+        }
+        dst[x] = v;
+    }
+}
+
+// biases of phase p for every workgroup: dst[bi][p*(3+nS)*8 + slot*8 + cg]
+//   slot 0,1: bg[c + h R] + sum_m br[m] Wg^cur[m][c + h R]   (folded gate bias, fp64)
+//   slot 2:   br[c] = ob[S + c];  slot 3+j: bs[c + j R] = ob[c + j R]  (phase 0: sb = decoder/skip bias)
+__global__ void pack_bias_kernel(const float* __restrict__ gw, const float* __restrict__ gb, const float* __restrict__ ob,
+                                 const float* __restrict__ sb, int ks, int R, int S, int nS, int nbias, int p, float* __restrict__ dst) {
+    const int nwg = R / CPB, nslot = 3 + nS;
+    const int n = nwg * nslot * CPB;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        const int cg = x % CPB, slot = (x / CPB) % nslot, bi = x / (CPB * nslot);
+        const int c = bi * CPB + cg;
+        float v = 0.0f;
+        if (slot < 2) {
+            if (gw && gb) {
+                double acc = gb[c + slot * R];
+                if (ob) {
+                    const float* gc = gw + (size_t)(ks - 1) * R * 2 * R;
+                    for (int m = 0; m < R; ++m) acc += (double)ob[S + m] * (double)gc[(size_t)m * 2 * R + c + slot * R];
+                }
+                v = (float)acc;
+            }
+        } else if (slot == 2) {
+            if (ob) v = ob[S + c];
+        } else {
+            const int j = slot - 3;
+            if (ob) v = ob[c + j * R];
+            else if (sb) v = sb[c + j * R];
+        }
+        dst[(size_t)bi * nbias + p * nslot * CPB + slot * CPB + cg] = v;
     }
 }
 
@@ -616,6 +739,15 @@ __global__ void pack_head_kernel(const float* __restrict__ src, int ld, int rows
         const int i = e / ncol, j = e % ncol;
         const int c = bi * CPB + (ct >> 5), k = (ct & 31) + 32 * i;
         dst[((size_t)bi * nhead + e0 + e) * NCT + ct] = (k < rows) ? src[(size_t)k * ld + c + j * R] : 0.0f;
+    }
+}
+
+// head biases: dst[bi][off + j*8 + cg] = src[c + j*R]
+__global__ void pack_head_bias_kernel(const float* __restrict__ src, int R, int ncol, int nbias, int off, float* __restrict__ dst) {
+    const int nwg = R / CPB, n = nwg * ncol * CPB;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
+        const int cg = x % CPB, j = (x / CPB) % ncol, bi = x / (CPB * ncol);
+        dst[(size_t)bi * nbias + off + j * CPB + cg] = src[bi * CPB + cg + j * R];
     }
 }
 
@@ -664,7 +796,7 @@ bool arp_supported(const vqw_ar_weights* w, int batch) {
     if (env && env[0] == '0') return false;
     if (w->R < 32 || w->R > 256 || w->R % 32 || w->S % w->R || w->Q % w->R) return false;
     const int nS = w->S / w->R, nQ = w->Q / w->R;
-    if (nQ < 1 || nQ > PJ || batch > PB || w->pre_k > 60 || w->kernel_size > KSMAX) return false;
+    if (nQ < 1 || nQ > PJ || batch > PB || w->pre_k > 60 || w->n_layers < 3) return false;
     if (!pick_kernel<1>(w->R / 32, nS, w->kernel_size)) return false;
     const Carve cv = make_carve(w->n_layers, w->kernel_size, w->R, w->S, w->Q, batch, nS, nQ, w->pre_k);
     if ((size_t)cv.total * sizeof(float) > 160 * 1024) return false;
@@ -686,62 +818,37 @@ int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const f
     const Carve cv = make_carve(L, ks, R, S, Q, batch, nS, nQ, w->pre_k);
     PArgs& a = h->args;
     memset(&a, 0, sizeof(a));
-    a.L = L; a.ks = ks; a.R = R; a.S = S; a.Q = Q; a.B = batch; a.nS = nS; a.nQ = nQ; a.pre_k = w->pre_k;
-    a.ngq = (ks * RL * 2 + 3) / 4;
-    a.noq = (RL * (nS + 1) + 3) / 4;
-    // ---- per-layer weight columns, blocked per compute thread
-    const size_t gstride = (size_t)nwg * a.ngq * NCT * 4, ostride = (size_t)nwg * a.noq * NCT * 4;
+    a.L = L; a.R = R; a.S = S; a.Q = Q; a.B = batch; a.nQ = nQ; a.pre_k = w->pre_k;
+    const int npw = ((ks - 1) * RL * 2 + 3) / 4, ncw = (RL * (5 + nS) + 3) / 4;
+    // ---- per-phase weight columns, blocked per compute thread; biases; head
+    const size_t pstride = (size_t)nwg * npw * NCT * 4, cstride = (size_t)nwg * ncw * NCT * 4;
     const size_t nheadw = (size_t)nwg * cv.nhead * NCT;
-    float* gw = (float*)pmalloc(h, L * gstride * sizeof(float));
-    float* ow = (float*)pmalloc(h, L * ostride * sizeof(float));
+    float* pw = (float*)pmalloc(h, (L + 1) * pstride * sizeof(float));
+    float* cw = (float*)pmalloc(h, (L + 1) * cstride * sizeof(float));
     float* hwd = (float*)pmalloc(h, nheadw * sizeof(float));
-    if (!gw || !ow || !hwd) return fail("hipMalloc failed");
-    for (int l = 0; l < L; ++l) {
-        hipLaunchKernelGGL(pack_gate_kernel, dim3(256), dim3(256), 0, 0, gated_w[l], ks, R, a.ngq, gw + l * gstride);
-        hipLaunchKernelGGL(pack_out_kernel, dim3(256), dim3(256), 0, 0, out_w[l], w->out_ld, R, S, nS, a.noq, ow + l * ostride);
+    float* db = (float*)pmalloc(h, (size_t)nwg * cv.nbias * sizeof(float));
+    if (!pw || !cw || !hwd || !db) return fail("hipMalloc failed");
+    for (int p = 0; p <= L; ++p) {
+        const float* gw = (p < L) ? gated_w[p] : nullptr;
+        const float* gb = (p < L) ? gated_b[p] : nullptr;
+        const float* ow = (p > 0) ? out_w[p - 1] : nullptr;
+        const float* ob = (p > 0) ? out_b[p - 1] : nullptr;
+        hipLaunchKernelGGL(pack_pw_kernel, dim3(256), dim3(256), 0, 0, gw, ks, R, npw, pw + p * pstride);
+        hipLaunchKernelGGL(pack_cw_kernel, dim3(512), dim3(256), 0, 0, gw, ow, (p == 0) ? w->skip0_w : nullptr, w->out_ld, ks, R, S, nS,
+                           ncw, cw + p * cstride);
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(8), dim3(256), 0, 0, gw, gb, ob, (p == 0) ? w->skip0_b : nullptr, ks, R, S, nS, cv.nbias, p,
+                           db);
     }
     int e0 = 0;
     hipLaunchKernelGGL(pack_head_kernel, dim3(256), dim3(256), 0, 0, w->post1_w, S, S, R, nS, hwd, e0, cv.nhead);
     e0 += cv.n_p1;
     hipLaunchKernelGGL(pack_head_kernel, dim3(256), dim3(256), 0, 0, w->post2_w, Q, S, R, nQ, hwd, e0, cv.nhead);
     e0 += cv.n_p2;
-    hipLaunchKernelGGL(pack_head_kernel, dim3(256), dim3(256), 0, 0, w->skip0_w, S, R, R, nS, hwd, e0, cv.nhead);
-    e0 += cv.n_s0;
     hipLaunchKernelGGL(pack_head_kernel, dim3(64), dim3(256), 0, 0, w->pre_w, R, w->pre_k, R, 1, hwd, e0, cv.nhead);
-    a.gw = gw; a.ow = ow; a.headw = hwd;
-    // ---- biases: tiny, packed on the host
-    {
-        std::vector<float> hb((size_t)nwg * cv.nbias, 0.0f), tmp;
-        auto fetch = [&](const float* dptr, int n) -> bool {
-            tmp.resize(n);
-            return hipMemcpy(tmp.data(), dptr, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
-        };
-        for (int l = 0; l < L; ++l) {
-            if (!fetch(gated_b[l], 2 * R)) return fail("hipMemcpy failed");
-            for (int bi = 0; bi < nwg; ++bi)
-                for (int hh = 0; hh < 2; ++hh)
-                    for (int g = 0; g < CPB; ++g)
-                        hb[(size_t)bi * cv.nbias + l * (nS + 3) * CPB + hh * CPB + g] = tmp[hh * R + bi * CPB + g];
-            if (!fetch(out_b[l], S + R)) return fail("hipMemcpy failed");
-            for (int bi = 0; bi < nwg; ++bi)
-                for (int j = 0; j <= nS; ++j)
-                    for (int g = 0; g < CPB; ++g)
-                        hb[(size_t)bi * cv.nbias + l * (nS + 3) * CPB + (2 + j) * CPB + g] = tmp[(j < nS ? j * R : S) + bi * CPB + g];
-        }
-        struct { const float* p; int n, ncol, at; } hs[] = {{w->skip0_b, S, nS, 0}, {w->post1_b, S, nS, nS},
-                                                           {w->post2_b, Q, nQ, 2 * nS}, {w->pre_b, R, 1, 2 * nS + nQ}};
-        for (auto& s : hs) {
-            if (!fetch(s.p, s.n)) return fail("hipMemcpy failed");
-            for (int bi = 0; bi < nwg; ++bi)
-                for (int j = 0; j < s.ncol; ++j)
-                    for (int g = 0; g < CPB; ++g)
-                        hb[(size_t)bi * cv.nbias + cv.bias_head + (s.at + j) * CPB + g] = tmp[j * R + bi * CPB + g];
-        }
-        float* db = (float*)pmalloc(h, hb.size() * sizeof(float));
-        if (!db) return fail("hipMalloc failed");
-        if (hipMemcpy(db, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
-        a.bias = db;
-    }
+    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->post1_b, R, nS, cv.nbias, cv.bias_head, db);
+    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->post2_b, R, nQ, cv.nbias, cv.bias_head + nS * CPB, db);
+    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->pre_b, R, 1, cv.nbias, cv.bias_head + (nS + nQ) * CPB, db);
+    a.pw = pw; a.cw = cw; a.headw = hwd; a.bias = db;
     // ---- rings (layer inputs == dilation queues) and exchange buffers
     {
         std::vector<int> roff(L);
@@ -761,7 +868,7 @@ int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const f
         if (!a.rings) return fail("hipMalloc failed");
         h->zero_on_reset.push_back({a.rings, (size_t)total * sizeof(u64)});
     }
-    struct { u64** p; size_t n; } exs[] = {{&a.ex_g, (size_t)batch * R}, {&a.ex_s, (size_t)batch * S},
+    struct { u64** p; size_t n; } exs[] = {{&a.ex_g, (size_t)2 * batch * R}, {&a.ex_s, (size_t)batch * S},
                                            {&a.ex_h, (size_t)batch * S}, {&a.ex_l, (size_t)batch * Q}};
     for (auto& e : exs) {
         *e.p = (u64*)pmalloc(h, e.n * sizeof(u64));
@@ -781,7 +888,7 @@ int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const f
     h->lds_bytes = (size_t)cv.total * sizeof(float);
     if (h->lds_bytes < 96 * 1024) h->lds_bytes = 96 * 1024;   // > half of the 160 KiB: one workgroup per CU
     if (h->lds_bytes > 160 * 1024) return fail("LDS budget exceeded");
-    h->kfn = (batch <= 1) ? pick_kernel<1>(RL, nS, ks) : pick_kernel<8>(RL, nS, ks);
+    h->kfn = (batch <= 1) ? pick_kernel<1>(RL, nS, ks) : pick_kernel<PB>(RL, nS, ks);
     if (!h->kfn) return fail("unsupported R/S combination");
     if (hipFuncSetAttribute(h->kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
         return fail("hipFuncSetAttribute failed");
@@ -820,9 +927,11 @@ int arp_error(ArPersist* h, hipStream_t st) {
         const int nw = h->nwg * 8;
         std::vector<u64> t((size_t)nw * 16);
         (void)hipMemcpy(t.data(), h->trace, t.size() * sizeof(u64), hipMemcpyDeviceToHost);
-        const int picks[4] = {0, 4, nw - 8, nw - 4};
-        for (int w : picks) {
-            fprintf(stderr, "[ar-trace] wave %3d (%s): us/sample by section:", w, (w & 7) < 4 ? "compute" : "gather");
+        const int picks[3] = {0, 4, 6};
+        const char* names[3] = {"compute", "fresh", "history"};
+        for (int k = 0; k < 3; ++k) {
+            const int w = picks[k];
+            fprintf(stderr, "[ar-trace] wave %3d (%s): us/sample by section:", w, names[k]);
             double tot = 0;
             for (int i = 0; i < 16; ++i) {
                 const double us = t[(size_t)w * 16 + i] * 0.01 / h->trace_steps;
