@@ -224,6 +224,20 @@ def main():
                "us_per_sample": gdt / a.gen_steps * 1e6}
         g.close()
         log('generation: %.1f us/sample' % (gdt / a.gen_steps * 1e6))
+        if world == 1:   # BASELINE.json configs[3] folded onto ONE GPU: 8 speakers x 1 utterance, rows as concurrent handles
+            enc8 = model.encode(x.contiguous(), spk.contiguous())
+            g8 = gen_mod.FastGenerator(model, batch=B)
+            g8.generate(enc8, 64)
+            torch.cuda.synchronize()
+            g8.reset()
+            t1 = time.perf_counter()
+            g8.generate(enc8, a.gen_steps)
+            torch.cuda.synchronize()
+            g8dt = time.perf_counter() - t1
+            g8.close()
+            gen["eight_utterances_one_gpu"] = {"value": B * a.gen_steps / g8dt, "unit": "samples/s", "utterances": B,
+                                               "us_per_step": g8dt / a.gen_steps * 1e6}
+            log('generation, %d utterances on one GPU: %.1f us/step' % (B, g8dt / a.gen_steps * 1e6))
 
     if rank == 0:
         R, ks = model.R, model.ks

@@ -272,6 +272,15 @@ int vqw_ar_decode_reset(vqw_ar_decoder* h, vqw_stream_t s);
 int vqw_ar_decode_run(vqw_ar_decoder* h, const float* encoding, int Tz, int ratio,
                       int n_steps, int mode, const float* uniforms, float* audio,
                       int32_t* indices, float* probs_last, vqw_stream_t s);
+/* The same, split: _run_async only enqueues (on the handle's own stream, ordered after the work already in `s`);
+ * _wait blocks the host until the enqueued run is done -- only then may the outputs be used, on any stream -- and
+ * reports a device-side failure (a spin-wait timeout of the persistent kernel).  vqw_ar_decode_run == _run_async
+ * + _wait.  Several handles started with _run_async generate concurrently (batches above 4 rows are split this
+ * way by the host code).                                                                                     */
+int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding, int Tz, int ratio,
+                            int n_steps, int mode, const float* uniforms, float* audio,
+                            int32_t* indices, float* probs_last, vqw_stream_t s);
+int vqw_ar_decode_wait(vqw_ar_decoder* h);
 int vqw_ar_decode_destroy(vqw_ar_decoder* h);
 
 #ifdef __cplusplus

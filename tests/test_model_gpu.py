@@ -189,6 +189,54 @@ def test_fast_generation_matches_oracle(pkg):
         pkg.generator.FastGenerator(model, batch=1).generate(enc[:1].contiguous(), 4, mode='beam')
 
 
+def test_fast_generation_reference_width(pkg):
+    """The persistent generator at the reference widths (R=256, S=512, 30 layers, dilations up to 512; the
+    kernel that bench.py times), teacher-forced against the oracle's FIFO-queue generator: every GPU decision is
+    the oracle's argmax within 2e-6 in probability, the final probabilities agree to rtol 2e-4.  The condition
+    frame changes inside the run (ratio 24) and the run is continued once (queue state carries over)."""
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    P = M.init_params(m, w, 109, seed=3, randomize_all=True)
+    model = build(pkg, m, w, 109, P)
+    n, ratio = 56, 24
+    enc = torch.randn(1, model.Cc, 3, generator=torch.Generator().manual_seed(5)) * 0.5     # [B][Cc][Tz]
+    gen = pkg.generator.FastGenerator(model, batch=1)
+    a1, i1 = gen.generate(enc.cuda(), 30, ratio=ratio)
+    a2, i2, probs = gen.generate(enc.cuda(), n - 30, ratio=ratio, return_probs=True)
+    gen.close()
+    got = torch.cat([i1, i2], 1).cpu().numpy()
+    ga = torch.cat([a1, a2], 1).cpu().numpy()
+    np.testing.assert_allclose(ga, M.R.mu_law_decode_np(got.astype(np.float32)), rtol=1e-5, atol=1e-6)
+    g = M.FastGenerator(P, w, 1)
+    a = np.zeros([1, 1], np.float32)
+    with torch.no_grad():
+        for i in range(n):
+            pr = g.step(torch.from_numpy(a), enc[:, :, min(i // ratio, 2)]).numpy()
+            assert pr[0].max() - pr[0, got[0, i]] <= 2e-6, 'step %d: GPU chose %d (p=%.8f), oracle argmax %d (p=%.8f)' % (
+                i, got[0, i], pr[0, got[0, i]], pr[0].argmax(), pr[0].max())
+            a = ga[:, i:i + 1]
+    np.testing.assert_allclose(probs.cpu().numpy(), pr, rtol=2e-4, atol=1e-7)
+
+
+def test_fast_generation_batch_split(pkg):
+    """Batches above 4 rows run as several persistent handles side by side (rows never interact,
+    generate.py:40): every row of a 6-row run equals the same row generated in a 2-row run, bit for bit."""
+    m, w = tiny_cfg()
+    P = M.init_params(m, w, 10, seed=11, randomize_all=True)
+    model = build(pkg, m, w, 10, P)
+    x, spk, _ = M.synthetic_batch(6, 512, 10, 77)
+    enc = model.encode(x[:, :, 0].contiguous().cuda(), spk.cuda())
+    u = torch.rand(6, 96, generator=torch.Generator().manual_seed(1)).cuda()
+    big = pkg.generator.FastGenerator(model, batch=6)
+    assert len(big._parts) == 2 and sum(big._parts) == 6
+    ab, ib = big.generate(enc, 96, mode='sample', uniforms=u)
+    big.close()
+    for r0 in (0, 2, 4):
+        small = pkg.generator.FastGenerator(model, batch=2)
+        a_s, i_s = small.generate(enc[r0:r0 + 2].contiguous(), 96, mode='sample', uniforms=u[r0:r0 + 2].contiguous())
+        small.close()
+        assert torch.equal(i_s, ib[r0:r0 + 2]) and torch.equal(a_s, ab[r0:r0 + 2])
+
+
 def test_magenta_encoder_model_parity(pkg):
     """Encoder_Magenta (encoder.py:29-63) wired into the same VQ + decoder: two full train steps."""
     m, w = tiny_cfg()

@@ -87,6 +87,8 @@ SIGNATURES = {
     'vqw_ar_decode_create': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i]),
     'vqw_ar_decode_reset': (_i, [_fp, _fp]),
     'vqw_ar_decode_run': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    'vqw_ar_decode_run_async': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    'vqw_ar_decode_wait': (_i, [_fp]),
     'vqw_ar_decode_destroy': (_i, [_fp]),
 }
 

@@ -326,6 +326,7 @@ struct vqw_ar_decoder {
     hipGraphExec_t gexec = nullptr;
     bool use_graph = true;
     ArPersist* persist = nullptr;  // persistent single-launch generator (default model shapes)
+    bool pending = false;          // a run has been enqueued and not yet waited for
 };
 
 namespace {
@@ -456,6 +457,10 @@ extern "C" int vqw_ar_decode_create(vqw_ar_decoder** out, const vqw_ar_weights* 
 
 extern "C" int vqw_ar_decode_reset(vqw_ar_decoder* h, vqw_stream_t s) {
     VQW_CHECK(h, "vqw_ar_decode_reset: null handle");
+    if (h->pending) {
+        const int rcw = vqw_ar_decode_wait(h);
+        if (rcw) return rcw;
+    }
     hipStream_t st = (hipStream_t)s;
     const size_t B = h->B;
     if (h->persist) {
@@ -470,10 +475,35 @@ extern "C" int vqw_ar_decode_reset(vqw_ar_decoder* h, vqw_stream_t s) {
     return 0;
 }
 
+extern "C" int vqw_ar_decode_wait(vqw_ar_decoder* h) {
+    VQW_CHECK(h, "vqw_ar_decode_wait: null handle");
+    if (!h->pending) return 0;
+    h->pending = false;
+    if (h->persist) {
+        const int rc = arp_error(h->persist, h->stream);
+        if (rc) return vqw_set_error("vqw_ar_decode_run: persistent kernel %s", rc > 0 ? "timed out waiting for a workgroup" : "failed");
+        return 0;
+    }
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int vqw_ar_decode_run(vqw_ar_decoder* h, const float* encoding, int Tz, int ratio, int n_steps,
                                  int mode, const float* uniforms, float* audio, int32_t* indices,
                                  float* probs_last, vqw_stream_t s) {
+    const int rc = vqw_ar_decode_run_async(h, encoding, Tz, ratio, n_steps, mode, uniforms, audio, indices, probs_last, s);
+    if (rc) return rc;
+    return vqw_ar_decode_wait(h);
+}
+
+extern "C" int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding, int Tz, int ratio, int n_steps,
+                                       int mode, const float* uniforms, float* audio, int32_t* indices,
+                                       float* probs_last, vqw_stream_t s) {
     VQW_CHECK(h && encoding, "vqw_ar_decode_run: null pointer");
+    if (h->pending) {
+        const int rcw = vqw_ar_decode_wait(h);
+        if (rcw) return rcw;
+    }
     VQW_CHECK(Tz > 0 && ratio > 0 && n_steps > 0, "vqw_ar_decode_run: bad Tz/ratio/n_steps");
     VQW_CHECK(mode == 0 || (mode == 1 && uniforms), "vqw_ar_decode_run: mode must be 0 (greedy) or 1 (sample, needs uniforms)");
     const vqw_ar_weights& w = h->w;
@@ -507,12 +537,9 @@ extern "C" int vqw_ar_decode_run(vqw_ar_decoder* h, const float* encoding, int T
         if (rc) return rc;
     }
     if (h->persist) {   // one launch for the whole run; waits for completion to report a spin-wait timeout
-        int rc = arp_run(h->persist, h->condenc.data(), Tz, ratio, n_steps, mode, uniforms, audio, indices, probs_last, st);
+        const int rc = arp_run(h->persist, h->condenc.data(), Tz, ratio, n_steps, mode, uniforms, audio, indices, probs_last, st);
         if (rc) return rc;
-        rc = arp_error(h->persist, st);
-        if (rc) return vqw_set_error("vqw_ar_decode_run: persistent kernel %s", rc > 0 ? "timed out waiting for a workgroup" : "failed");
-        HIPC(hipEventRecord(h->ev_out, st));
-        HIPC(hipStreamWaitEvent(user, h->ev_out, 0));
+        h->pending = true;   // the caller's stream is NOT made to wait: that would serialise handles started back to back
         return 0;
     }
     // run parameters -> device state (step / run_base live on the device)
@@ -544,8 +571,7 @@ extern "C" int vqw_ar_decode_run(vqw_ar_decoder* h, const float* encoding, int T
             if (rc) return rc;
         }
     }
-    HIPC(hipEventRecord(h->ev_out, st));
-    HIPC(hipStreamWaitEvent(user, h->ev_out, 0));
+    h->pending = true;
     return 0;
 }
 

@@ -8,11 +8,19 @@ import torch
 from . import _lib as L
 
 
+MAX_ROWS = 4   # batch rows of one persistent launch (its LDS budget); larger batches run as several handles
+
+
 class FastGenerator:
     def __init__(self, model, batch):
         """Uses the model's LIVE variables (call model.use_ema_weights() first to mirror
-        generate.py:88-90, which restores the EMA shadows)."""
+        generate.py:88-90, which restores the EMA shadows).  Rows of the batch never interact
+        (generate.py:40,103-113), so a batch above MAX_ROWS is cut into independent handles whose
+        persistent kernels (R/8 workgroups each) run side by side on the chip."""
         self.model, self.B = model, batch
+        n_parts = -(-batch // MAX_ROWS)
+        base, extra = divmod(batch, n_parts)
+        self._parts = [base + (1 if i < extra else 0) for i in range(n_parts)]
         P = model.P
         nl, R, S = model.L, model.R, model.S
         w = L.ArWeights()
@@ -37,12 +45,16 @@ class FastGenerator:
         w.post1_cond_w, w.post1_cond_ld = P['cond_w'].data_ptr() + nl * 2 * R * f4, model.Mall
         w.post2_w, w.post2_b = P['post2_w'].data_ptr(), P['post2_b'].data_ptr()
         self._w = w
-        self._h = C.c_void_p()
-        L.check(L.lib().vqw_ar_decode_create(C.byref(self._h), C.byref(w), batch))
+        self._hs = []
+        for nb in self._parts:
+            h = C.c_void_p()
+            L.check(L.lib().vqw_ar_decode_create(C.byref(h), C.byref(w), nb))
+            self._hs.append(h)
 
     def reset(self):
         """sess.run(wavenet.init_ops) (generate.py:105)."""
-        L.check(L.lib().vqw_ar_decode_reset(self._h, L.stream()))
+        for h in self._hs:
+            L.check(L.lib().vqw_ar_decode_reset(h, L.stream()))
 
     def generate(self, encoding, n_steps, mode='greedy', uniforms=None, ratio=None, return_probs=False):
         """encoding [B][Cc][Tz] (model.encode); continues from the current queue state.
@@ -63,14 +75,23 @@ class FastGenerator:
                 uniforms = torch.rand(B, n_steps, device=dev)        # np.random.rand in utils.py:22
             if uniforms.shape != (B, n_steps) or uniforms.dtype != torch.float32:
                 raise ValueError('uniforms must be float32 [B][n_steps]')
-        L.check(L.lib().vqw_ar_decode_run(self._h, L.ptr(encoding), Tz, ratio, n_steps, 0 if mode == 'greedy' else 1,
-                                          L.ptr(uniforms), L.ptr(audio), L.ptr(idx), L.ptr(probs), L.stream()))
+        encoding = encoding.contiguous()
+        b0 = 0
+        for h, nb in zip(self._hs, self._parts):     # enqueue every part, then wait: the parts generate concurrently
+            rows = slice(b0, b0 + nb)
+            L.check(L.lib().vqw_ar_decode_run_async(
+                h, L.ptr(encoding[rows]), Tz, ratio, n_steps, 0 if mode == 'greedy' else 1,
+                L.ptr(uniforms[rows]) if uniforms is not None else None, L.ptr(audio[rows]), L.ptr(idx[rows]),
+                L.ptr(probs[rows]) if probs is not None else None, L.stream()))
+            b0 += nb
+        for h in self._hs:
+            L.check(L.lib().vqw_ar_decode_wait(h))
         return (audio, idx, probs) if return_probs else (audio, idx)
 
     def close(self):
-        if self._h:
-            L.lib().vqw_ar_decode_destroy(self._h)
-            self._h = C.c_void_p()
+        for h in getattr(self, '_hs', []):
+            L.lib().vqw_ar_decode_destroy(h)
+        self._hs = []
 
     def __del__(self):
         try:
