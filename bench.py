@@ -252,7 +252,7 @@ def main():
                                    "(fwd+bwd+allreduce+Adam+EMA)" % (T, B),
                        "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
             "loss": loss,
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<2,2,GATE> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate)",
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<2,2,GATE> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; LDS-DMA pipeline, half-width tail tiles)",
                          "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": hbm_traffic(),
                          "ms_per_launch": gate_ms, "flop_per_launch": flops_gate,

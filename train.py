@@ -74,7 +74,7 @@ def main():
         raise NotImplementedError('dataset %s not implemented' % args.dataset)
 
     parameters, wavenet_parameters = pkg.model.load_configs(args.parameter_path)
-    if parameters['encoder'] not in ('64',):
+    if parameters['encoder'] not in ('64', 'Magenta', '2019'):                      # train.py:52-60
         raise NotImplementedError('encoder %s not implemented' % parameters['encoder'])
     model = pkg.model.VQVAE(parameters, wavenet_parameters, dataset.num_speakers, device=dev, seed=0)
     if args.restore_path is not None:
