@@ -261,7 +261,7 @@ def main():
         if gen:
             rec["ar_gen"] = gen
         if world == 1 and not a.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(1, T, 2)
+            rec["cpu_baseline"] = cpu_baseline(1, T, 12)          # ~10 s of host work
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -218,6 +218,61 @@ def test_gate_epilogue_with_condition(K, T, tile):
     close(th * sg, out, atol=1e-6, rtol=0, what='saved tanh*sigmoid')
 
 
+@pytest.mark.parametrize('d', [1, 8, 512])
+def test_gate_conv_full_size_properties(K, d):
+    """BASELINE.json configs[1] sizes (B=8, T=6656, 256 -> 512, k=3): the grid the bench runs (LDS-DMA interior
+    blocks, register-pipeline edge blocks, half-width tail tiles).  Size-independent checks: (1) sampled outputs
+    against an fp64 evaluation of wavenet_ops.py:81-113 at those points; (2) causality -- perturbing x at
+    t >= t0 leaves every output at t < t0 bit-identical; (3) saved tanh * sigmoid == gated."""
+    B, T, Rr, ratio = 8, 6656, 256, 64
+    Tz = T // ratio
+    gen = torch.Generator().manual_seed(10 + d)
+    x = torch.randn(B, Rr, T, generator=gen)
+    w = torch.randn(3, Rr, 2 * Rr, generator=gen) * 0.05
+    b = torch.randn(2 * Rr, generator=gen) * 0.3
+    cond = torch.randn(B, 2 * Rr, Tz, generator=gen) * 0.3
+    xd, wd, bd, cd = x.to(DEV), w.to(DEV), b.to(DEV), cond.to(DEV)
+    out = torch.empty(B, Rr, T, device=DEV); th = torch.empty_like(out); sg = torch.empty_like(out)
+    args = dict(w=wd, bias=bd, save0=th, save1=sg, B=B, T_in=T, T_out=T, M=2 * Rr, C0=Rr, taps=[-2 * d, -d, 0],
+                epilogue=K.EPI_GATE, cond=cd, cond_T=Tz)
+    K.conv_gemm(x0=xd, out0=out, **args)
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert float((th * sg - out).abs().max()) <= 1e-6
+    # (1) sampled points, biased towards the edges of the signal and of the tiles
+    g2 = torch.Generator().manual_seed(99)
+    n = 3000
+    bb = torch.randint(0, B, (n,), generator=g2)
+    cc = torch.randint(0, Rr, (n,), generator=g2)
+    tt = torch.randint(0, T, (n,), generator=g2)
+    tt[:300] = torch.randint(0, 2 * d + 2, (300,), generator=g2).clamp(max=T - 1)
+    tt[300:600] = T - 1 - torch.randint(0, 130, (300,), generator=g2)
+    tt[600:900] = (torch.randint(0, T // 128, (300,), generator=g2) * 128 + torch.randint(-1, 2, (300,), generator=g2)).clamp(0, T - 1)
+    x64, w64 = x.double(), w.double()
+    worst = 0.0
+    for i in range(n):
+        bi, ci, ti = int(bb[i]), int(cc[i]), int(tt[i])
+        pre = torch.zeros(2, dtype=torch.float64)
+        for j, sh in enumerate((-2 * d, -d, 0)):
+            if ti + sh >= 0:
+                xv = x64[bi, :, ti + sh]
+                pre[0] += (xv * w64[j, :, ci]).sum()
+                pre[1] += (xv * w64[j, :, Rr + ci]).sum()
+        pre[0] += float(b[ci]) + float(cond[bi, ci, ti // ratio])
+        pre[1] += float(b[Rr + ci]) + float(cond[bi, Rr + ci, ti // ratio])
+        want = float(torch.tanh(pre[0]) * torch.sigmoid(pre[1]))
+        worst = max(worst, abs(float(got[bi, ci, ti]) - want))
+    assert worst < 2e-5, 'sampled gate outputs differ from fp64 evaluation by %.3e' % worst
+    # (2) causality
+    t0 = 4001
+    x2 = xd.clone()
+    x2[:, :, t0:] += 1.0
+    out2 = torch.empty_like(out)
+    K.conv_gemm(x0=x2, out0=out2, **args)
+    assert torch.equal(out2[:, :, :t0], out[:, :, :t0]), 'outputs before t0 changed'
+    assert not torch.equal(out2[:, :, t0:], out[:, :, t0:])
+
+
 def test_accum_split_and_two_sources(K):
     B, T, Cg, S, Rr = 2, 512, 32, 64, 32
     gated, w, b = rnd(B, T, Cg, seed=1), rnd(Cg, S + Rr, seed=2, s=0.2), rnd(S + Rr, seed=3)

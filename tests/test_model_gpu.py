@@ -269,3 +269,5 @@ def test_mfcc_kernel_matches_oracle(pkg):
     got = out[:, :13].permute(0, 2, 1).cpu()
     assert float((got - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max()))
     assert float(out[:, 13:].abs().max()) == 0.0
+    assert torch.equal(pkg.ops.mfcc(xb).cpu(), got)                  # the reference-named op (encoder_ops.py:14)
+    assert pkg.encoders.Encoder_2019 is pkg.encoders.Encoder2019 and pkg.encoders.Encoder_Magenta is pkg.encoders.EncoderMagenta

@@ -317,3 +317,8 @@ class Encoder2019:
         K.bn_relu_bwd(da[0], a[0], ones, da[0])
         K.rowsum(da[0], total=G['e19_b'][0])
         K.wgrad_gemm(p=ws['e_mf'], q0=da[0], dw=G['e19_w0'], B=B, T_q=Fr, T_p=Fr, Cp=self.CPAD, Q0=F, taps=k3)
+
+
+# the reference's class names (Encoder/encoder.py:29,66)
+Encoder_Magenta = EncoderMagenta
+Encoder_2019 = Encoder2019

@@ -147,6 +147,20 @@ def linear_64(net, kernel, bias):
     return _keras_conv1d(net, kernel, bias, 1, False)
 
 
+def mfcc(audio, mel=None):
+    """encoder_ops.py:14-43: audio [B,T] -> [B, ceil(T/160), 13] (STFT 400/160 hann, pad_end, 201 bins ->
+    80 mel bins 20-8000 Hz -> log(. + 1e-6) -> DCT-II -> first 13), one vqw_mfcc launch."""
+    from .encoders import mel_weight_matrix
+    audio = audio.contiguous()
+    B, T = audio.shape
+    if mel is None:
+        mel = mel_weight_matrix().to(audio.device)
+    frames = -(-T // 160)
+    out = torch.empty(B, 13, frames, device=audio.device)
+    K.mfcc(audio, mel.contiguous(), out, n_keep=13)
+    return _btc(out)
+
+
 def concat(net, global_condition):
     """decoder_ops.py:39-43."""
     return torch.cat([net, global_condition.expand(-1, net.shape[1], -1)], dim=-1)
