@@ -88,6 +88,8 @@ typedef struct vqw_conv_desc {
                          + 10000*n: the last n main-tile columns of every row are computed
                          by tiles half as wide at the end of the same grid (load balance;
                          chosen automatically when n is not given)                        */
+    int32_t split_k;  /* 0 = auto, 1 = none, n > 1: every tile's K range is cut over n blocks that
+                         meet by fp32 atomics (plain STORE epilogue only; out0 is zeroed first) */
     int64_t cond_bstride; /* batch stride of cond in floats                              */
     int64_t w_tap_stride; /* floats between consecutive taps of w; 0 = (C0+C1)*ldw       */
     const float *x0, *x1, *w, *bias, *cond, *scale, *shift, *aux0, *aux1;

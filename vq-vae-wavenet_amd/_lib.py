@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
         ('tap_shift', C.c_int32 * MAX_TAPS), ('ldw', C.c_int32), ('in_relu', C.c_int32),
         ('epilogue', C.c_int32), ('out_relu', C.c_int32), ('M0', C.c_int32),
         ('out_tstride', C.c_int32), ('out_toffset', C.c_int32), ('T_store', C.c_int32),
-        ('cond_T', C.c_int32), ('tile', C.c_int32), ('cond_bstride', C.c_int64),
+        ('cond_T', C.c_int32), ('tile', C.c_int32), ('split_k', C.c_int32), ('cond_bstride', C.c_int64),
         ('w_tap_stride', C.c_int64),
         ('x0', _fp), ('x1', _fp), ('w', _fp), ('bias', _fp), ('cond', _fp), ('scale', _fp),
         ('shift', _fp), ('aux0', _fp), ('aux1', _fp),

@@ -55,6 +55,7 @@ struct ConvArgs {
     int ratio;   // cond: T_out / cond_T
     int vec_ok;  // output rows allow aligned vector stores
     int use_dma; // LDS-DMA pipeline for interior blocks (VQW_CONV_DMA=0 disables it)
+    int ksplit;  // > 1: the K range of every tile is cut over ksplit blocks, partial tiles meet by fp32 atomics
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -100,7 +101,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rowp, int tb,
 
 // One output tile.  `smem` holds NST stages of BK*(BM+BN) floats (the caller's ONE LDS array).
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem, const int bid, const BlockGrid g) {
+__device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem, const int bid, const BlockGrid g, const int ks) {
     constexpr int BM = 64 * MT, BN = 64 * NT;
     constexpr int A_F4 = (BK * BM / 4) / 256;  // float4 per thread, weight tile
     constexpr int B_F4 = (BK * BN / 4) / 256;  // float4 per thread, activation tile
@@ -141,7 +142,18 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
             if (hi >= 0 && lo < d.T_in) { act |= 1u << j; ++nact; }
         }
     }
-    const int nsteps = nact * kchunks;
+    // split-K (linear STORE only): this block multiplies K-steps [s_begin, s_begin + nsteps) of the tile
+    const int nsteps_all = nact * kchunks;
+    const int s_begin = (a.ksplit > 1) ? (int)((long)ks * nsteps_all / a.ksplit) : 0;
+    const int nsteps = (a.ksplit > 1) ? (int)((long)(ks + 1) * nsteps_all / a.ksplit) - s_begin : nsteps_all;
+    auto first_pos = [&](int& tap, int& kc) {   // (tap, channel block) of K-step s_begin
+        tap = -1;
+        for (int i = 0; i <= s_begin / kchunks; ++i) {
+            ++tap;
+            while (tap < d.ntaps && !((act >> tap) & 1u)) ++tap;
+        }
+        kc = (s_begin % kchunks) * BK;
+    };
 
     // Staging registers.  A "piece" is what one thread moves per K-step in one go: one float4
     // of activations, or one float4 of weights (GATE: the matching filter+gate float4 pair).
@@ -289,7 +301,8 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
     // straight-line version for blocks whose active taps are all interior and a generic one
     // for the few blocks that touch the left/right edge of the signal.
     auto k_loop = [&](auto fast_tag) {
-        int ld_tap = next_tap(-1), ld_kc = 0;
+        int ld_tap, ld_kc;
+        first_pos(ld_tap, ld_kc);
         auto advance = [&]() {
             ld_kc += BK;
             if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
@@ -393,7 +406,8 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
             const int f = (wid * B_F4 + q) * 256 + 4 * lane;
             vb[q] = ((f / BN) * d.T_in + (f % BN)) * 4;
         }
-        int ld_tap = next_tap(-1), ld_kc = 0;
+        int ld_tap, ld_kc;
+        first_pos(ld_tap, ld_kc);
         auto advance = [&]() {
             ld_kc += BK;
             if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
@@ -529,6 +543,14 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
                 for (int f = 0; f < NT; ++f) v[f] = acc[e][f][rho];
 
                 if constexpr (EPI == VQW_EPI_STORE) {
+                    if (a.ksplit > 1) {   // partial tile: the launcher zeroed out0 and vetted the epilogue as linear
+                        const float bv0 = (ks == 0 && d.bias) ? d.bias[row] : 0.0f;
+                        float* dst = d.out0 + ((size_t)b * d.M + row) * Ts;
+#pragma unroll
+                        for (int f = 0; f < NT; ++f)
+                            if (tb + f < d.T_out) unsafeAtomicAdd(dst + tstr * (tb + f) + toff, v[f] + bv0);
+                        continue;
+                    }
                     const float bv = d.bias ? d.bias[row] : 0.0f;
 #pragma unroll
                     for (int f = 0; f < NT; ++f) {
@@ -606,11 +628,16 @@ template <int MT, int NT, int EPI>
 __global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int NST = 3;
     __shared__ __attribute__((aligned(16))) float smem[NST * BK * 64 * (MT + NT)];
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x, ks = 0;
+    if (a.ksplit > 1) {
+        const int ntiles = a.main.nwg + a.tail.nwg;
+        ks = bid / ntiles;
+        bid -= ks * ntiles;
+    }
     if (bid < a.main.nwg) {
-        conv_block<MT, NT, EPI>(a, smem, bid, a.main);
+        conv_block<MT, NT, EPI>(a, smem, bid, a.main, ks);
     } else {
-        if constexpr (NT > 1) conv_block<MT, NT / 2, EPI>(a, smem, bid - a.main.nwg, a.tail);
+        if constexpr (NT > 1) conv_block<MT, NT / 2, EPI>(a, smem, bid - a.main.nwg, a.tail, ks);
     }
 }
 
@@ -630,7 +657,7 @@ int launch_cfg(ConvArgs& a, hipStream_t st, int tail_nt) {
         a.tail.nwg = n_mt * a.tail.n_nt * d.B;
         a.tail.t_begin = t_main;
     }
-    dim3 grid(a.main.nwg + a.tail.nwg), block(256);
+    dim3 grid((a.main.nwg + a.tail.nwg) * (a.ksplit > 1 ? a.ksplit : 1)), block(256);
     switch (d.epilogue) {
         case VQW_EPI_STORE:
             hipLaunchKernelGGL((conv_gemm_kernel<MT, NT, VQW_EPI_STORE>), grid, block, 0, st, a);
@@ -718,15 +745,49 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
     static const int dma_env = [] { const char* e = getenv("VQW_CONV_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
     a.use_dma = dma_env;
     hipStream_t st = static_cast<hipStream_t>(s);
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const bool gate = d.epilogue == VQW_EPI_GATE;
+    auto nblocks = [&](int t) {
+        const int mt = t / 10, nt = t % 10;
+        return (long)(gate ? vqw_cdiv(a.H, 32 * mt) : vqw_cdiv(d.M, 64 * mt)) * vqw_cdiv(d.T_out, 64 * nt) * d.B;
+    };
     int tile = d.tile;
     if (tile == 0) {
-        const int rows = (d.epilogue == VQW_EPI_GATE) ? d.M : d.M;
-        const int mt = (rows <= 64 && d.epilogue != VQW_EPI_GATE) ? 1 : 2;
-        // wide time tiles when there is enough work to fill the chip with them
-        const long blocks_wide = (long)vqw_cdiv(rows, 64 * mt) * vqw_cdiv(d.T_out, 256) * d.B;
-        (void)blocks_wide;
-        const int ntile = 2;
-        tile = 10 * mt + ntile;
+        // the widest tile that still gives the chip a round and a half of blocks: the short layers of the encoder
+        // (T_out down to 104) ran 48..192 blocks of 128x128 on 256 CUs at 13..43 TFLOP/s
+        tile = 22;
+        if (gate) {
+            if (nblocks(22) * 2 < 3L * cus) tile = 21;
+        } else {
+            if (d.M <= 64) tile = 12;
+            if (nblocks(tile) * 2 < 3L * cus) tile = 12;
+            if (nblocks(tile) * 2 < 3L * cus) tile = 11;
+        }
+    }
+    // split-K for a linear STORE whose tiles cannot fill the chip but whose K loop is long (the input gradient of
+    // the 31 stacked condition projections: 128 x 104 outputs per batch row, K = 15 872: 8 blocks, 1.4 ms)
+    a.ksplit = 1;
+    {
+        const bool linear = d.epilogue == VQW_EPI_STORE && !d.out_relu && !d.scale && d.cond_T == 0 && !d.save0 && !d.aux1 &&
+                            d.M0 == d.M && d.out_tstride == 1 && d.out_toffset == 0;
+        const long ksteps = (long)d.ntaps * ((d.C0 + d.C1) / BK);
+        int want = d.split_k;
+        if (want == 0 && linear) {
+            const long nb = nblocks(tile % 100);
+            if (nb * 2 <= cus && ksteps >= 64) {
+                want = (int)((2L * cus + nb - 1) / nb);
+                if (want > ksteps / 16) want = (int)(ksteps / 16);
+            }
+        }
+        if (want > 1) {
+            VQW_CHECK(linear, "vqw_conv_gemm: split_k needs a plain STORE epilogue (bias only)");
+            if (want > ksteps) want = (int)ksteps;
+            a.ksplit = want;
+        }
     }
     // A GEMM whose block count leaves a thin last round (B*T = 13*2^12 makes every tiling a multiple of 13
     // blocks; measured on the gate conv: two full rounds of 768 blocks, then 128 blocks on a mostly idle chip)
@@ -734,11 +795,6 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
     // big blocks of the last full round retire and spread over all CUs.  Explicit form of `tile`:
     // main + 10000*(main-tile columns given to the half-width tiles); VQW_CONV_TAIL=0 disables the auto choice.
     static const int tail_env = [] { const char* e = getenv("VQW_CONV_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
     const int main_tile = tile % 100;
     int tail_nt = tile / 10000;
     const int mtm = main_tile / 10, ntm = main_tile % 10;
@@ -749,6 +805,10 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
         const long slots = (long)cus * occ, per_col = (long)n_mt * d.B, nblk = per_col * vqw_cdiv(d.T_out, 64 * ntm);
         const long rem = nblk % slots;
         if (nblk > slots && rem > 0 && rem * 10 < slots * 7) tail_nt = (int)((rem + per_col - 1) / per_col);
+    }
+    if (a.ksplit > 1) {
+        hipError_t e_ = hipMemsetAsync(d.out0, 0, (size_t)d.B * d.M * d.T_store * sizeof(float), st);
+        if (e_ != hipSuccess) return vqw_set_error("vqw_conv_gemm: hipMemsetAsync failed: %s", hipGetErrorString(e_));
     }
     switch (main_tile) {
         case 24: return launch_cfg<2, 4>(a, st, tail_nt);

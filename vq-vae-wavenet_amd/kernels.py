@@ -24,7 +24,7 @@ def _need(t, n, what):
 def conv_gemm(*, x0, w, out0, B, T_in, T_out, M, C0, taps, x1=None, C1=0, in_stride=1, ldw=None,
               in_relu=False, epilogue=EPI_STORE, out_relu=False, M0=0, out_tstride=1, out_toffset=0,
               T_store=0, cond=None, cond_T=0, cond_bstride=0, w_tap_stride=0, bias=None, scale=None,
-              shift=None, aux0=None, aux1=None, out1=None, save0=None, save1=None, tile=0):
+              shift=None, aux0=None, aux1=None, out1=None, save0=None, save1=None, tile=0, split_k=0):
     """vqw_conv_gemm (include/vqwave.h).  `taps` = list of input shifts per tap."""
     ldw = M if ldw is None else ldw
     Ts = T_store if T_store > 0 else out_tstride * T_out
@@ -84,6 +84,7 @@ def conv_gemm(*, x0, w, out0, B, T_in, T_out, M, C0, taps, x1=None, C1=0, in_str
     d.ldw, d.in_relu, d.epilogue, d.out_relu, d.M0 = ldw, int(in_relu), epilogue, int(out_relu), M0
     d.out_tstride, d.out_toffset, d.T_store = out_tstride, out_toffset, T_store
     d.cond_T, d.tile, d.cond_bstride, d.w_tap_stride = cond_T, tile, cond_bstride, w_tap_stride
+    d.split_k = split_k
     for name, t in (('x0', x0), ('x1', x1), ('w', w), ('bias', bias), ('cond', cond), ('scale', scale),
                     ('shift', shift), ('aux0', aux0), ('aux1', aux1), ('out0', out0), ('out1', out1),
                     ('save0', save0), ('save1', save1)):
