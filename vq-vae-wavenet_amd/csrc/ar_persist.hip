@@ -41,7 +41,6 @@ namespace {
 typedef unsigned long long u64;
 constexpr int PB = 4;        // max batch rows of one persistent launch (LDS budget; larger batches: several handles)
 constexpr int PJ = 8;        // max Q / R
-constexpr int CPB = 8;       // channels per workgroup
 constexpr int NCT = 256;     // compute threads (waves 0-3)
 constexpr int NGL = 128;     // lanes of the fresh role (waves 4-5) and of the history role (waves 6-7)
 constexpr unsigned long long TIMEOUT_TICKS = 300000000ull;  // 3 s of s_memrealtime (100 MHz)
@@ -72,13 +71,13 @@ struct PArgs {
 
 // LDS carve (in floats), shared by the host (size) and the device (offsets)
 struct Carve {
-    int xfresh, xpast, hx1, hx2, hw, bias, condc, xh, misc, tab, total;
+    int xfresh, xpast, hx1, hx2, hw, bias, condc, xh, misc, tab, dtab, total;
     int n_p1, n_p2, n_pre, nhead, nbias, bias_head, npast;
 };
-__host__ __device__ inline Carve make_carve(int L, int ks, int R, int S, int Q, int B, int nS, int nQ, int pre_k) {
+__host__ __device__ inline Carve make_carve(int L, int ks, int R, int S, int Q, int B, int nS, int nQ, int pre_k, int CPB) {
     Carve c;
-    const int SL = S / 32;
-    c.n_p1 = SL * nS; c.n_p2 = SL * nQ; c.n_pre = (pre_k + 31) / 32;
+    const int LPC = NCT / CPB, SL = S / LPC;             // lanes per channel, rows of an S-long column per lane
+    c.n_p1 = SL * nS; c.n_p2 = SL * nQ; c.n_pre = (pre_k + LPC - 1) / LPC;
     c.nhead = c.n_p1 + c.n_p2 + c.n_pre;
     c.bias_head = (L + 1) * (nS + 3) * CPB;              // per phase: folded gate bias {f, g}, residual bias, skip biases
     c.nbias = c.bias_head + (nS + nQ + 1) * CPB;         // post1, post2, preprocess
@@ -94,7 +93,8 @@ __host__ __device__ inline Carve make_carve(int L, int ks, int R, int S, int Q, 
     c.xh = c.condc + (L * 2 + nS) * CPB * B;
     c.misc = c.xh + ((B * pre_k + 3) & ~3);
     c.tab = c.misc + 64;
-    c.total = c.tab + 2 * L;
+    c.dtab = c.tab + 2 * L;                              // mu-law decode / re-encode of every class index 0..Q
+    c.total = c.dtab + 2 * (Q + 1);
     return c;
 }
 
@@ -170,28 +170,30 @@ __device__ __forceinline__ void gather_segs(int gid, int* fail, const u64* const
     }
 }
 
-// Sum over the 32 lanes of a half wave with DPP only (full-rate VALU, no LDS round trip): four steps inside each
-// row of 16, then row_bcast15 adds row 0's total into row 1 (and row 2's into row 3).  The total is valid in
-// lanes 16-31 / 48-63: the publishing lane of a channel is its lane 31.
+// Sum over the lanes of a channel with DPP only (full-rate VALU, no LDS round trip): four steps inside each row
+// of 16, then row_bcast15 adds row 0's total into row 1 (and row 2's into row 3), and for a channel that owns the
+// whole wave row_bcast31 adds lane 31's total into rows 2-3.  The total is valid in the channel's last lane,
+// which publishes.
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false));
 }
-__device__ __forceinline__ float half_sum(float v) {
+template <int LPC>
+__device__ __forceinline__ float chan_sum(float v) {   // sum over the LPC (32 or 64) lanes of a channel; valid in its last lane
     v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
     v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
     v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
     v = dpp_add<0x140, 0xF>(v);   // row_mirror
     v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    if constexpr (LPC == 64) v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
     return v;
 }
-constexpr int PUBL = 31;          // lane (within the half wave) that holds a channel's sums and publishes them
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // softmax + sampling + mu-law decode of the batch rows this wave owns (row b -> wave b): utils.py:13-46,
 // mu_law_ops.py:26-31.  Every workgroup does it redundantly (identical bits everywhere); xh receives
 // x_in(t+1) = mu_law_encode(decoded sample)  (wavenet.py:113).
-__device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int t, int it, float* xg, float* xh) {
+__device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int t, int it, float* xg, float* xh, const float* dtab) {
     const int wv = tid >> 6, lane = tid & 63, Q = a.Q;
     for (int b = wv; b < a.B; b += 8) {
         float* lg = xg + (size_t)b * Q;
@@ -238,8 +240,8 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
                     if (cdf < u) idx = q + 1;
                 }
             }
-            const float dec = p_mu_dec((float)idx);
-            xh[b * a.pre_k + ((t + 1) % a.pre_k)] = p_mu_enc(dec);
+            const float dec = dtab[idx];                   // p_mu_dec(idx), p_mu_enc(that): tabulated once per launch
+            xh[b * a.pre_k + ((t + 1) % a.pre_k)] = dtab[Q + 1 + idx];
             if (bi == 0) {
                 if (a.audio) a.audio[(size_t)b * a.n_steps + it] = dec;
                 if (a.indices) a.indices[(size_t)b * a.n_steps + it] = idx;
@@ -262,23 +264,26 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
 #define TR_DUMP
 #endif
 
-// TB: compile-time bound of the batch rows; RLT = R/32 rows of a weight column per lane; NS = S/R; KS taps.
+// TB: compile-time bound of the batch rows; CPB channels per workgroup, i.e. LPC = 256/CPB lanes per channel;
+// RLT = R/LPC rows of a weight column per lane; NS = S/R; KS taps.
 // (Compile-time load counts let the compiler wait with exact vmcnt values: with a run-time count it falls back to
 // vmcnt(0) in front of the first use, i.e. waits for the loads it has requested a moment earlier.)
-template <int TB, int RLT, int NS, int KS>
+template <int TB, int RLT, int NS, int KS, int CPB>
 __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
     extern __shared__ float lds[];
-    constexpr int SL = RLT * NS;                          // S / 32
+    constexpr int LPC = NCT / CPB;                        // lanes per channel
+    constexpr int PUBL = LPC - 1;                         // the lane that ends up with a channel's sums and publishes them
+    constexpr int SL = RLT * NS;                          // S / LPC
     constexpr int NCOL = 5 + NS;                          // critical columns per weight row: Wg f,g | M f,g | Wr | Ws..
     constexpr int NPW = ((KS - 1) * RLT * 2 + 3) / 4;     // float4 groups per thread: past taps
     constexpr int NCW = (RLT * NCOL + 3) / 4;             // float4 groups per thread: critical columns
     const int bi = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
     const int role = tid >> 8 ? (tid >> 7) - 1 : 0;       // 0 compute (tid < 256), 1 fresh (256..383), 2 history (384..511)
     const int ct = tid & (NCT - 1);
-    const int cg = ct >> 5, kl = ct & 31;
+    const int cg = ct / LPC, kl = ct % LPC;
     const int c = bi * CPB + cg;                          // compute thread's channel
     const int B = a.B, R = a.R, S = a.S, Q = a.Q, L = a.L, nQ = a.nQ;
-    const Carve cv = make_carve(L, KS, R, S, Q, B, NS, nQ, a.pre_k);
+    const Carve cv = make_carve(L, KS, R, S, Q, B, NS, nQ, a.pre_k, CPB);
     float* const xfresh = lds + cv.xfresh;                // [2][{cur_{p-1}, gated_{p-1}}][B][R]
     float* const xpast = lds + cv.xpast;                  // [3][KS-1][B][R]
     float* const hx1 = lds + cv.hx1;                      // relu(skip) [B][S], later the logits [B][Q]
@@ -300,6 +305,11 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
     for (int i = tid; i < L; i += 512) { tab[i] = a.dil[i]; tab[L + i] = a.ring_off[i]; }
     for (int i = tid; i < B * a.pre_k; i += 512) xh[i] = a.xhist[i];
     if (tid == 0) *fail = 0;
+    for (int i = tid; i <= Q; i += 512) {
+        const float dec = p_mu_dec((float)i);
+        lds[cv.dtab + i] = dec;
+        lds[cv.dtab + Q + 1 + i] = p_mu_enc(dec);
+    }
     __syncthreads();
     if (tid < B) xh[tid * a.pre_k + (t0 % a.pre_k)] = p_mu_enc(a.prev[tid]);   // x_in(t0) = mu_law_encode(previous sample)
     __syncthreads();
@@ -339,22 +349,23 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
             const unsigned seq = (unsigned)t * (unsigned)PH + 1u;
             const unsigned ttag = (unsigned)t + 1u;
             if (p == 0) {
-                // ---------------- preprocess: causal conv over the encoded input history, lane kl = tap kl (+32)
+                // ---------------- preprocess: causal conv over the encoded input history, lane kl = tap kl (+LPC)
                 const int depth0 = (KS - 1) * tab[0] + 1;
                 u64* ring0 = a.rings + tab[L] + (size_t)(t % depth0) * nBR;
+                const int tm1 = t % a.pre_k + 1;           // slot of x_in(t - (pre_k-1-j)) = (t + 1 + j) mod pre_k, no division per tap
 #pragma unroll
                 for (int b = 0; b < TB; ++b) {
                     if (b < B) {
                         float acc = 0.0f;
                         for (int i = 0; i < cv.n_pre; ++i) {
-                            const int j = kl + 32 * i;
+                            const int j = kl + LPC * i;
                             if (j < a.pre_k) {
-                                const int tau = t - (a.pre_k - 1 - j);
-                                const int slot = ((tau % a.pre_k) + a.pre_k) % a.pre_k;
+                                int slot = tm1 + j;
+                                if (slot >= a.pre_k) slot -= a.pre_k;
                                 acc = fmaf(hw_pre[i * NCT + ct], xh[b * a.pre_k + slot], acc);
                             }
                         }
-                        cur[b] = half_sum(acc) + bs[cv.bias_head + (NS + nQ) * CPB + cg];
+                        cur[b] = chan_sum<LPC>(acc) + bs[cv.bias_head + (NS + nQ) * CPB + cg];
                         if (kl == PUBL) publish(ring0 + (size_t)b * R + c, ttag, cur[b]);
 #pragma unroll
                         for (int j = 0; j < NS; ++j) skipacc[j][b] = 0.0f;
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                         for (int j = 0; j < KS - 1; ++j) {
 #pragma unroll
                             for (int i = 0; i < RLT; ++i) {
-                                const float xv = xp[(j * B + b) * R + kl + 32 * i];
+                                const float xv = xp[(j * B + b) * R + kl + LPC * i];
                                 const int e = (j * RLT + i) * 2;
                                 pf[b] = fmaf(pw[e >> 2][e & 3], xv, pf[b]);
                                 pg[b] = fmaf(pw[(e + 1) >> 2][(e + 1) & 3], xv, pg[b]);
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                     for (int j = 0; j < NS; ++j) sk[j] = 0.0f;
 #pragma unroll
                     for (int i = 0; i < RLT; ++i) {
-                        const float xa = vA[b * R + kl + 32 * i], xv = vB[b * R + kl + 32 * i];
+                        const float xa = vA[b * R + kl + LPC * i], xv = vB[b * R + kl + LPC * i];
                         const int e = i * NCOL;
                         f = fmaf(cw[e >> 2][e & 3], xa, f);
                         g = fmaf(cw[(e + 1) >> 2][(e + 1) & 3], xa, g);
@@ -431,9 +442,9 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
 #pragma unroll
                         for (int j = 0; j < NS; ++j) sk[j] = fmaf(cw[(e + 5 + j) >> 2][(e + 5 + j) & 3], xv, sk[j]);
                     }
-                    f = half_sum(f);
-                    g = half_sum(g);
-                    r = half_sum(r);
+                    f = chan_sum<LPC>(f);
+                    g = chan_sum<LPC>(g);
+                    r = chan_sum<LPC>(r);
                     cur[b] += r + brv;                     // net = net + (residual conv + bias)  (wavenet_ops.py:266)
                     if (kl == PUBL && p < L) {
                         const float vf = f + cf[b];
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                     }
 #pragma unroll
                     for (int j = 0; j < NS; ++j) {
-                        skipacc[j][b] += half_sum(sk[j]) + bl[(3 + j) * CPB + cg];   // skip = skip + (skip conv + bias)
+                        skipacc[j][b] += chan_sum<LPC>(sk[j]) + bl[(3 + j) * CPB + cg];   // skip = skip + (skip conv + bias)
                         if (p == L && kl == PUBL) publish(a.ex_s + (size_t)b * S + c + (size_t)j * R, seq + L, skipacc[j][b]);
                     }
                     if (TB > 1) __builtin_amdgcn_sched_barrier(0);
@@ -470,8 +481,8 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                         for (int j = 0; j < NS; ++j) {
                             float s = 0.0f;
 #pragma unroll
-                            for (int i = 0; i < SL; ++i) s = fmaf(hw_p1[(i * NS + j) * NCT + ct], hx1[b * S + kl + 32 * i], s);
-                            s = half_sum(s);
+                            for (int i = 0; i < SL; ++i) s = fmaf(hw_p1[(i * NS + j) * NCT + ct], hx1[b * S + kl + LPC * i], s);
+                            s = chan_sum<LPC>(s);
                             if (kl == PUBL) {
                                 const float v = s + bs[cv.bias_head + j * CPB + cg] + condc[((L * 2 + j) * CPB + cg) * B + b];
                                 publish(a.ex_h + (size_t)b * S + c + (size_t)j * R, seq + L + 1, v);
@@ -489,8 +500,8 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                         for (int j = 0; j < nQ; ++j) {
                             float s = 0.0f;
 #pragma unroll
-                            for (int i = 0; i < SL; ++i) s = fmaf(hw_p2[(i * nQ + j) * NCT + ct], hx2[b * S + kl + 32 * i], s);
-                            s = half_sum(s);
+                            for (int i = 0; i < SL; ++i) s = fmaf(hw_p2[(i * nQ + j) * NCT + ct], hx2[b * S + kl + LPC * i], s);
+                            s = chan_sum<LPC>(s);
                             if (kl == PUBL) publish(a.ex_l + (size_t)b * Q + c + (size_t)j * R, seq + L + 2, s + bs[cv.bias_head + (NS + j) * CPB + cg]);
                         }
                     }
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                 TR(8)
                 role_barrier();                            // BAR_H3: hx1 = logits [B][Q]
                 TR(9)
-                decode_rows(a, bi, tid, t, it, hx1, xh);
+                decode_rows(a, bi, tid, t, it, hx1, xh, lds + cv.dtab);
                 TR(10)
                 if (*reinterpret_cast<volatile int*>(fail)) stop = true;   // stable between BAR_H3 and BAR_H4: nobody polls there
                 role_barrier();                            // BAR_H4: xh holds x_in(t+1)
@@ -624,7 +635,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                 }
                 TR(5)
                 role_barrier();                            // BAR_H3
-                decode_rows(a, bi, tid, t, it, hx1, xh);
+                decode_rows(a, bi, tid, t, it, hx1, xh, lds + cv.dtab);
                 if (*reinterpret_cast<volatile int*>(fail)) stop = true;
                 role_barrier();                            // BAR_H4
                 TR(6)
@@ -650,31 +661,31 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
 // one-time re-blocking of the model's variables: every compute thread's share becomes contiguous.
 // Phase p in 0..L: gate of layer p (p < L), residual + skip of layer p-1 (p > 0; phase 0: skip = linear(cur_0)).
 
-// past-tap gate columns: dst[bi][q][ct][4]; element e = q*4+r = (tap*RL + i)*2 + h, taps 0..ks-2
-__global__ void pack_pw_kernel(const float* __restrict__ gw, int ks, int R, int npw, float* __restrict__ dst) {
-    const int RL = R / 32, nwg = R / CPB;
+// past-tap gate columns: dst[bi][q][ct][4]; element e = q*4+r = (tap*RL + i)*2 + h, taps 0..ks-2, RL = R/LPC rows per lane
+__global__ void pack_pw_kernel(const float* __restrict__ gw, int ks, int R, int npw, int CPB, float* __restrict__ dst) {
+    const int LPC = NCT / CPB, RL = R / LPC, nwg = R / CPB;
     const size_t n = (size_t)nwg * npw * NCT * 4;
     for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(x & 3), ct = (int)((x >> 2) % NCT), q = (int)((x / (4 * NCT)) % npw), bi = (int)(x / ((size_t)4 * NCT * npw));
         const int e = q * 4 + r, h = e & 1, i = (e >> 1) % RL, j = (e >> 1) / RL;
-        const int c = bi * CPB + (ct >> 5), k = (ct & 31) + 32 * i;
+        const int c = bi * CPB + ct / LPC, k = ct % LPC + LPC * i;
         dst[x] = (gw && j < ks - 1) ? gw[((size_t)j * R + k) * 2 * R + c + h * R] : 0.0f;
     }
 }
 
-// critical columns: dst[bi][q][ct][4]; e = i*(5+nS) + col, weight row k = kl + 32 i:
+// critical columns: dst[bi][q][ct][4]; e = i*(5+nS) + col, weight row k = kl + LPC i:
 //   col 0,1: Wg^cur[k][c + h R]                      (gw: gate kernel [ks][R][2R] of layer p, or null)
 //   col 2,3: M[k][c + h R] = sum_m Wr[k][m] Wg^cur[m][c + h R]   (fp64 accumulation; needs gw and ow)
 //   col 4:   Wr[k][c] = ow[k][S + c]                 (ow: [R][ld] skip | residual of layer p-1, or null)
 //   col 5+j: Ws[k][c + j R] = ow[k][c + j R]         (phase 0: sw = decoder/skip kernel [R][S], ld = S)
 __global__ void pack_cw_kernel(const float* __restrict__ gw, const float* __restrict__ ow, const float* __restrict__ sw,
-                               int ld, int ks, int R, int S, int nS, int ncw, float* __restrict__ dst) {
-    const int RL = R / 32, nwg = R / CPB, ncol = 5 + nS;
+                               int ld, int ks, int R, int S, int nS, int ncw, int CPB, float* __restrict__ dst) {
+    const int LPC = NCT / CPB, RL = R / LPC, nwg = R / CPB, ncol = 5 + nS;
     const size_t n = (size_t)nwg * ncw * NCT * 4;
     for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(x & 3), ct = (int)((x >> 2) % NCT), q = (int)((x / (4 * NCT)) % ncw), bi = (int)(x / ((size_t)4 * NCT * ncw));
         const int e = q * 4 + r, i = e / ncol, col = e % ncol;
-        const int c = bi * CPB + (ct >> 5), k = (ct & 31) + 32 * i;
+        const int c = bi * CPB + ct / LPC, k = ct % LPC + LPC * i;
         float v = 0.0f;
         if (i < RL) {
             const float* gc = gw ? gw + (size_t)(ks - 1) * R * 2 * R : nullptr;   // current tap [R][2R]
@@ -702,7 +713,8 @@ __global__ void pack_cw_kernel(const float* __restrict__ gw, const float* __rest
 //   slot 0,1: bg[c + h R] + sum_m br[m] Wg^cur[m][c + h R]   (folded gate bias, fp64)
 //   slot 2:   br[c] = ob[S + c];  slot 3+j: bs[c + j R] = ob[c + j R]  (phase 0: sb = decoder/skip bias)
 __global__ void pack_bias_kernel(const float* __restrict__ gw, const float* __restrict__ gb, const float* __restrict__ ob,
-                                 const float* __restrict__ sb, int ks, int R, int S, int nS, int nbias, int p, float* __restrict__ dst) {
+                                 const float* __restrict__ sb, int ks, int R, int S, int nS, int nbias, int p, int CPB,
+                                 float* __restrict__ dst) {
     const int nwg = R / CPB, nslot = 3 + nS;
     const int n = nwg * nslot * CPB;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
@@ -729,21 +741,22 @@ __global__ void pack_bias_kernel(const float* __restrict__ gw, const float* __re
     }
 }
 
-// head section: src [rows][ld], ncol columns per channel (c + j*R) -> dst[bi][e0 + e][ct], e = i*ncol + j, row kl + 32 i
+// head section: src [rows][ld], ncol columns per channel (c + j*R) -> dst[bi][e0 + e][ct], e = i*ncol + j, row kl + LPC i
 __global__ void pack_head_kernel(const float* __restrict__ src, int ld, int rows, int R, int ncol, float* __restrict__ dst,
-                                 int e0, int nhead) {
-    const int nwg = R / CPB, nsec = ((rows + 31) / 32) * ncol;
+                                 int e0, int nhead, int CPB) {
+    const int LPC = NCT / CPB, nwg = R / CPB, nsec = ((rows + LPC - 1) / LPC) * ncol;
     const size_t n = (size_t)nwg * nsec * NCT;
     for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) {
         const int ct = (int)(x % NCT), e = (int)((x / NCT) % nsec), bi = (int)(x / ((size_t)NCT * nsec));
         const int i = e / ncol, j = e % ncol;
-        const int c = bi * CPB + (ct >> 5), k = (ct & 31) + 32 * i;
+        const int c = bi * CPB + ct / LPC, k = ct % LPC + LPC * i;
         dst[((size_t)bi * nhead + e0 + e) * NCT + ct] = (k < rows) ? src[(size_t)k * ld + c + j * R] : 0.0f;
     }
 }
 
 // head biases: dst[bi][off + j*8 + cg] = src[c + j*R]
-__global__ void pack_head_bias_kernel(const float* __restrict__ src, int R, int ncol, int nbias, int off, float* __restrict__ dst) {
+__global__ void pack_head_bias_kernel(const float* __restrict__ src, int R, int ncol, int nbias, int off, int CPB,
+                                      float* __restrict__ dst) {
     const int nwg = R / CPB, n = nwg * ncol * CPB;
     for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n; x += gridDim.x * blockDim.x) {
         const int cg = x % CPB, j = (x / CPB) % ncol, bi = x / (CPB * ncol);
@@ -757,21 +770,40 @@ __global__ void pack_head_bias_kernel(const float* __restrict__ src, int R, int 
         if (e_ != hipSuccess) return vqw_set_error("%s failed: %s", #x, hipGetErrorString(e_)); \
     } while (0)
 
+// channels per workgroup: 4 (a whole wave per channel, R/4 workgroups: half the weight stream per CU and half the
+// dot-product length per lane) where R allows it and the chip has the CUs, else 8; VQW_AR_CPB overrides
+int pick_cpb(int R, int cus) {
+    int cpb = (R % 64 == 0 && R / 4 <= cus) ? 4 : 8;
+    const char* env = getenv("VQW_AR_CPB");
+    if (env && (env[0] == '4' || env[0] == '8')) cpb = env[0] - '0';
+    if (cpb == 4 && R % 64) cpb = 8;
+    return cpb;
+}
+
 template <int TB>
-const void* pick_kernel(int RL, int nS, int ks) {
-#define ARP_CASE(rl, ns, k) \
-    if (RL == rl && nS == ns && ks == k) return reinterpret_cast<const void*>(ar_persist_kernel<TB, rl, ns, k>)
-    ARP_CASE(8, 2, 3); ARP_CASE(4, 2, 3); ARP_CASE(2, 2, 3); ARP_CASE(1, 2, 3); ARP_CASE(8, 1, 3); ARP_CASE(4, 4, 3);
-    ARP_CASE(8, 2, 2); ARP_CASE(1, 2, 2);
+const void* pick_kernel(int R, int nS, int ks, int cpb) {
+    const int RL = R / (NCT / cpb);
+#define ARP_CASE(rl, ns, k, cp) \
+    if (RL == rl && nS == ns && ks == k && cpb == cp) return reinterpret_cast<const void*>(ar_persist_kernel<TB, rl, ns, k, cp>)
+    ARP_CASE(4, 2, 3, 4); ARP_CASE(4, 2, 2, 4); ARP_CASE(2, 2, 3, 4); ARP_CASE(1, 2, 3, 4);
+    ARP_CASE(8, 2, 3, 8); ARP_CASE(4, 2, 3, 8); ARP_CASE(2, 2, 3, 8); ARP_CASE(1, 2, 3, 8); ARP_CASE(8, 1, 3, 8); ARP_CASE(4, 4, 3, 8);
+    ARP_CASE(8, 2, 2, 8); ARP_CASE(1, 2, 2, 8);
 #undef ARP_CASE
     return nullptr;   // other shapes run on the launch-per-phase path of ar_decode.hip
+}
+
+int device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
 }
 
 }  // namespace
 
 struct ArPersist {
     vqw_ar_weights w;
-    int B = 0, nS = 0, nQ = 0, nwg = 0;
+    int B = 0, nS = 0, nQ = 0, nwg = 0, cpb = 8;
     std::vector<void*> allocs;
     const float** dcond = nullptr;   // device copy of the L+1 condition pointers
     PArgs args;
@@ -797,13 +829,16 @@ bool arp_supported(const vqw_ar_weights* w, int batch) {
     if (w->R < 32 || w->R > 256 || w->R % 32 || w->S % w->R || w->Q % w->R) return false;
     const int nS = w->S / w->R, nQ = w->Q / w->R;
     if (nQ < 1 || nQ > PJ || batch > PB || w->pre_k > 60 || w->n_layers < 3) return false;
-    if (!pick_kernel<1>(w->R / 32, nS, w->kernel_size)) return false;
-    const Carve cv = make_carve(w->n_layers, w->kernel_size, w->R, w->S, w->Q, batch, nS, nQ, w->pre_k);
+    const int cus = device_cus();
+    if (cus <= 0) return false;
+    int cpb = pick_cpb(w->R, cus);
+    if (!pick_kernel<1>(w->R, nS, w->kernel_size, cpb)) {
+        cpb = 8;
+        if (!pick_kernel<1>(w->R, nS, w->kernel_size, cpb)) return false;
+    }
+    const Carve cv = make_carve(w->n_layers, w->kernel_size, w->R, w->S, w->Q, batch, nS, nQ, w->pre_k, cpb);
     if ((size_t)cv.total * sizeof(float) > 160 * 1024) return false;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return w->R / CPB <= cus;   // one resident workgroup per CU is what makes the spin-waits safe
+    return w->R / cpb <= cus;   // one resident workgroup per CU is what makes the spin-waits safe
 }
 
 int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const float* const* gated_w,
@@ -812,10 +847,13 @@ int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const f
     h->w = *w;
     h->B = batch;
     const int L = w->n_layers, R = w->R, S = w->S, Q = w->Q, ks = w->kernel_size;
-    const int nS = S / R, nQ = Q / R, RL = R / 32, nwg = R / CPB;
-    h->nS = nS; h->nQ = nQ; h->nwg = nwg;
+    const int nS = S / R, nQ = Q / R;
+    int CPB = pick_cpb(R, device_cus());
+    if (!pick_kernel<1>(R, nS, ks, CPB)) CPB = 8;
+    const int RL = R / (NCT / CPB), nwg = R / CPB;
+    h->nS = nS; h->nQ = nQ; h->nwg = nwg; h->cpb = CPB;
     auto fail = [&](const char* m) { arp_destroy(h); return vqw_set_error("vqw_ar_decode_create(persistent): %s", m); };
-    const Carve cv = make_carve(L, ks, R, S, Q, batch, nS, nQ, w->pre_k);
+    const Carve cv = make_carve(L, ks, R, S, Q, batch, nS, nQ, w->pre_k, CPB);
     PArgs& a = h->args;
     memset(&a, 0, sizeof(a));
     a.L = L; a.R = R; a.S = S; a.Q = Q; a.B = batch; a.nQ = nQ; a.pre_k = w->pre_k;
@@ -833,21 +871,21 @@ int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const f
         const float* gb = (p < L) ? gated_b[p] : nullptr;
         const float* ow = (p > 0) ? out_w[p - 1] : nullptr;
         const float* ob = (p > 0) ? out_b[p - 1] : nullptr;
-        hipLaunchKernelGGL(pack_pw_kernel, dim3(256), dim3(256), 0, 0, gw, ks, R, npw, pw + p * pstride);
+        hipLaunchKernelGGL(pack_pw_kernel, dim3(256), dim3(256), 0, 0, gw, ks, R, npw, CPB, pw + p * pstride);
         hipLaunchKernelGGL(pack_cw_kernel, dim3(512), dim3(256), 0, 0, gw, ow, (p == 0) ? w->skip0_w : nullptr, w->out_ld, ks, R, S, nS,
-                           ncw, cw + p * cstride);
+                           ncw, CPB, cw + p * cstride);
         hipLaunchKernelGGL(pack_bias_kernel, dim3(8), dim3(256), 0, 0, gw, gb, ob, (p == 0) ? w->skip0_b : nullptr, ks, R, S, nS, cv.nbias, p,
-                           db);
+                           CPB, db);
     }
     int e0 = 0;
-    hipLaunchKernelGGL(pack_head_kernel, dim3(256), dim3(256), 0, 0, w->post1_w, S, S, R, nS, hwd, e0, cv.nhead);
+    hipLaunchKernelGGL(pack_head_kernel, dim3(256), dim3(256), 0, 0, w->post1_w, S, S, R, nS, hwd, e0, cv.nhead, CPB);
     e0 += cv.n_p1;
-    hipLaunchKernelGGL(pack_head_kernel, dim3(256), dim3(256), 0, 0, w->post2_w, Q, S, R, nQ, hwd, e0, cv.nhead);
+    hipLaunchKernelGGL(pack_head_kernel, dim3(256), dim3(256), 0, 0, w->post2_w, Q, S, R, nQ, hwd, e0, cv.nhead, CPB);
     e0 += cv.n_p2;
-    hipLaunchKernelGGL(pack_head_kernel, dim3(64), dim3(256), 0, 0, w->pre_w, R, w->pre_k, R, 1, hwd, e0, cv.nhead);
-    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->post1_b, R, nS, cv.nbias, cv.bias_head, db);
-    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->post2_b, R, nQ, cv.nbias, cv.bias_head + nS * CPB, db);
-    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->pre_b, R, 1, cv.nbias, cv.bias_head + (nS + nQ) * CPB, db);
+    hipLaunchKernelGGL(pack_head_kernel, dim3(64), dim3(256), 0, 0, w->pre_w, R, w->pre_k, R, 1, hwd, e0, cv.nhead, CPB);
+    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->post1_b, R, nS, cv.nbias, cv.bias_head, CPB, db);
+    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->post2_b, R, nQ, cv.nbias, cv.bias_head + nS * CPB, CPB, db);
+    hipLaunchKernelGGL(pack_head_bias_kernel, dim3(8), dim3(256), 0, 0, w->pre_b, R, 1, cv.nbias, cv.bias_head + (nS + nQ) * CPB, CPB, db);
     a.pw = pw; a.cw = cw; a.headw = hwd; a.bias = db;
     // ---- rings (layer inputs == dilation queues) and exchange buffers
     {
@@ -888,7 +926,7 @@ int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const f
     h->lds_bytes = (size_t)cv.total * sizeof(float);
     if (h->lds_bytes < 96 * 1024) h->lds_bytes = 96 * 1024;   // > half of the 160 KiB: one workgroup per CU
     if (h->lds_bytes > 160 * 1024) return fail("LDS budget exceeded");
-    h->kfn = (batch <= 1) ? pick_kernel<1>(RL, nS, ks) : pick_kernel<PB>(RL, nS, ks);
+    h->kfn = (batch <= 1) ? pick_kernel<1>(R, nS, ks, CPB) : pick_kernel<PB>(R, nS, ks, CPB);
     if (!h->kfn) return fail("unsupported R/S combination");
     if (hipFuncSetAttribute(h->kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
         return fail("hipFuncSetAttribute failed");
