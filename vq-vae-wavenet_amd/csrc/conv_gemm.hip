@@ -413,6 +413,9 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
             if (ld_kc == Ctot) { ld_kc = 0; ld_tap = next_tap(ld_tap); }
         };
         auto dma = [&](int q, int st) {   // piece q of tile (ld_tap, ld_kc) -> stage st
+#ifdef VQW_ABL_NODMA
+            return;   // timing ablation only: operands never staged, wrong results
+#endif
             if (q < A_F4) {
                 const int soff = (int)(((long)ld_tap * d.w_tap_stride + (long)ld_kc * d.ldw) * 4);
                 vqw_buf_load_lds16(rsw, smem + st * STG + (wid * A_F4 + q) * 256, va[q], soff);
@@ -498,6 +501,9 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
     // ------------------------------------------------------------------ epilogue
     const int tb = t0 + wn * (NT * 32) + NT * l31;  // first of this lane's NT output times
     if (tb >= d.T_out) return;
+#ifdef VQW_ABL_NOEPI
+    if (acc[0][0][0] != 12345.678f) return;   // timing ablation only: no epilogue, wrong results
+#endif
     const int Ts = d.T_store;
     const int tstr = d.out_tstride, toff = d.out_toffset, vok = a.vec_ok;
 
