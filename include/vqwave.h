@@ -89,7 +89,9 @@ typedef struct vqw_conv_desc {
                          by tiles half as wide at the end of the same grid (load balance;
                          chosen automatically when n is not given)                        */
     int32_t split_k;  /* 0 = auto, 1 = none, n > 1: every tile's K range is cut over n blocks that
-                         meet by fp32 atomics (plain STORE epilogue only; out0 is zeroed first) */
+                         meet by fp32 atomics (plain STORE epilogue only; out0 is zeroed first);
+                         -n: the same, but the CALLER has zeroed out0 (strided outputs written by
+                         several launches)                                                       */
     int64_t cond_bstride; /* batch stride of cond in floats                              */
     int64_t w_tap_stride; /* floats between consecutive taps of w; 0 = (C0+C1)*ldw       */
     const float *x0, *x1, *w, *bias, *cond, *scale, *shift, *aux0, *aux1;
@@ -175,6 +177,11 @@ int vqw_rowsum(const float* x, const float* y, float* seg_out, float* total, flo
  *   dz[b][c][t] = dx[b][c][t] * scale[c] * (r ? (r[b][c][t] > 0) : 1);  dz may alias dx.    */
 int vqw_bn_relu_bwd(const float* dx, const float* r, const float* scale, float* dz, int B,
                     int C, int T, vqw_stream_t s);
+
+/* relu -> BatchNorm(inference affine) in place (encoder.py:15-20), the second pass of a split-K layer:
+ *   r[b][c][t] = relu(x) (optional);  x := scale[c]*relu(x) + shift[c]  (scale NULL: x := relu(x))     */
+int vqw_relu_bn_fwd(float* x, float* r, const float* scale, const float* shift, int B, int C, int T,
+                    vqw_stream_t s);
 
 /* MFCC front end of Encoder_2019 (encoder_ops.py:14-43): STFT (frame 400, step 160, periodic hann,
  * zero pad at the end: frames = ceil(T/160)) -> magnitude (201 bins) -> mel [201][n_mel] (device

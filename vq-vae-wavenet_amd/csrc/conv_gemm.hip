@@ -777,12 +777,14 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
     // split-K for a linear STORE whose tiles cannot fill the chip but whose K loop is long (the input gradient of
     // the 31 stacked condition projections: 128 x 104 outputs per batch row, K = 15 872: 8 blocks, 1.4 ms)
     a.ksplit = 1;
+    bool caller_zeroed = false;
     {
         const bool linear = d.epilogue == VQW_EPI_STORE && !d.out_relu && !d.scale && d.cond_T == 0 && !d.save0 && !d.aux1 &&
-                            d.M0 == d.M && d.out_tstride == 1 && d.out_toffset == 0;
+                            d.M0 == d.M;
         const long ksteps = (long)d.ntaps * ((d.C0 + d.C1) / BK);
-        int want = d.split_k;
-        if (want == 0 && linear) {
+        int want = d.split_k < 0 ? -d.split_k : d.split_k;
+        caller_zeroed = d.split_k < 0;
+        if (want == 0 && linear && d.out_tstride == 1 && d.out_toffset == 0) {
             const long nb = nblocks(tile % 100);
             if (nb * 2 <= cus && ksteps >= 64) {
                 want = (int)((2L * cus + nb - 1) / nb);
@@ -812,7 +814,7 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
         const long rem = nblk % slots;
         if (nblk > slots && rem > 0 && rem * 10 < slots * 7) tail_nt = (int)((rem + per_col - 1) / per_col);
     }
-    if (a.ksplit > 1) {
+    if (a.ksplit > 1 && !caller_zeroed) {
         hipError_t e_ = hipMemsetAsync(d.out0, 0, (size_t)d.B * d.M * d.T_store * sizeof(float), st);
         if (e_ != hipSuccess) return vqw_set_error("vqw_conv_gemm: hipMemsetAsync failed: %s", hipGetErrorString(e_));
     }

@@ -299,6 +299,19 @@ __global__ void bn_relu_bwd_kernel(const float* __restrict__ dx, const float* __
     }
 }
 
+// ----------------------------------------------------------------------------- relu/BN forward
+// Second pass of a split-K encoder layer (encoder.py:15-20): x holds conv + bias; r = relu(x) is saved for the
+// backward pass, x := scale[c] * r + shift[c] (BatchNorm in inference mode).
+__global__ void relu_bn_fwd_kernel(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, int C, int T, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / T) % C);
+        const float v = fmaxf(x[i], 0.0f);
+        if (r) r[i] = v;
+        x[i] = scale ? scale[c] * v + shift[c] : v;
+    }
+}
+
 // ----------------------------------------------------------------------------- transpose
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
                                  int cols) {
@@ -511,6 +524,15 @@ extern "C" int vqw_bn_relu_bwd(const float* dx, const float* r, const float* sca
     const size_t n = (size_t)B * C * T;
     hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, dx, r, scale, dz, C, T, n);
     VQW_LAUNCH_CHECK("vqw_bn_relu_bwd");
+    return 0;
+}
+
+extern "C" int vqw_relu_bn_fwd(float* x, float* r, const float* scale, const float* shift, int B, int C, int T,
+                               vqw_stream_t s) {
+    VQW_CHECK(x && B > 0 && C > 0 && T > 0 && (!scale || shift), "vqw_relu_bn_fwd: bad arguments");
+    const size_t n = (size_t)B * C * T;
+    hipLaunchKernelGGL(relu_bn_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, x, r, scale, shift, C, T, n);
+    VQW_LAUNCH_CHECK("vqw_relu_bn_fwd");
     return 0;
 }
 

@@ -182,6 +182,18 @@ def bn_relu_bwd(dx, r, scale, dz):
     L.check(L.lib().vqw_bn_relu_bwd(L.ptr(dx), L.ptr(r), L.ptr(scale), L.ptr(dz), B, Cc, T, L.stream()))
 
 
+def relu_bn_fwd(x, r, scale, shift):
+    """In place: r = relu(x) (optional), x = scale[c]*relu(x) + shift[c]."""
+    B, Cc, T = x.shape
+    L.require_cuda(x, r, scale, shift)
+    if r is not None:
+        _need(r, x.numel(), 'r')
+    if scale is not None:
+        _need(scale, Cc, 'scale')
+        _need(shift, Cc, 'shift')
+    L.check(L.lib().vqw_relu_bn_fwd(L.ptr(x), L.ptr(r), L.ptr(scale), L.ptr(shift), B, Cc, T, L.stream()))
+
+
 def mfcc(x, mel, out, *, n_keep=13):
     """x [B][T], mel [201][n_mel] -> out [B][C_out][ceil(T/160)] (channels >= n_keep zeroed)."""
     B, T = x.shape

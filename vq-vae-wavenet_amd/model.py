@@ -327,15 +327,31 @@ class VQVAE:
         for i in range(1, 6):
             Tout = ws['Tl'][i]
             pl, _ = same_pads(Tin, 5, 2)
-            K.conv_gemm(x0=ws['X'][i - 1], w=P['enc_w'][i - 1], bias=P['enc_b'][i], out0=ws['X'][i],
-                        save0=ws['r'][i] if save else None, scale=sc[i * F:(i + 1) * F], shift=sh[i * F:(i + 1) * F],
-                        B=B, T_in=Tin, T_out=Tout, M=F, C0=F, in_stride=2, taps=[j - pl for j in range(5)],
-                        out_relu=True)
+            nsplit = self._short_layer_split(F, Tout, B)
+            if nsplit > 1:
+                # short layer (T_out down to 104): too few tiles for 256 CUs, but K = 5*768 is long: split-K into the
+                # output buffer (plain STORE + atomics), then relu / save / BatchNorm affine as a second, tiny pass
+                K.conv_gemm(x0=ws['X'][i - 1], w=P['enc_w'][i - 1], bias=P['enc_b'][i], out0=ws['X'][i], B=B, T_in=Tin,
+                            T_out=Tout, M=F, C0=F, in_stride=2, taps=[j - pl for j in range(5)], tile=12, split_k=nsplit)
+                K.relu_bn_fwd(ws['X'][i], ws['r'][i] if save else None, sc[i * F:(i + 1) * F], sh[i * F:(i + 1) * F])
+            else:
+                K.conv_gemm(x0=ws['X'][i - 1], w=P['enc_w'][i - 1], bias=P['enc_b'][i], out0=ws['X'][i],
+                            save0=ws['r'][i] if save else None, scale=sc[i * F:(i + 1) * F], shift=sh[i * F:(i + 1) * F],
+                            B=B, T_in=Tin, T_out=Tout, M=F, C0=F, in_stride=2, taps=[j - pl for j in range(5)],
+                            out_relu=True)
             Tin = Tout
         Tz = ws['Tz']
         K.conv_gemm(x0=ws['X'][5], w=P['enc_w6'], bias=P['enc_b6'], out0=ws['z_e'], save0=ws['y6'] if save else None,
                     scale=sc[6 * F:], shift=sh[6 * F:], B=B, T_in=Tz, T_out=Tz, M=D, C0=F, taps=[0])
         self._quantise(spk, ws)
+
+    @staticmethod
+    def _short_layer_split(M, T_out, B, cus=256):
+        """K slices for a conv whose 64x128 tiles (4 resident per CU) cannot fill the chip: aim at ~4 blocks per CU."""
+        nb = -(-M // 64) * -(-T_out // 128) * B
+        if nb * 2 > 4 * cus:
+            return 1
+        return max(1, min(8, (4 * cus) // nb))
 
     def _quantise(self, spk, ws):
         """model.py:57-74 (VQ) + model.py:22-27 / decoder_ops.py:39-43 (speaker embedding tiled over time)."""
@@ -508,12 +524,16 @@ class VQVAE:
             K.wgrad_gemm(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], B=B, T_q=Ti, T_p=Tin, Cp=F, Q0=F, p_stride=2,
                          taps=[j - pl for j in range(5)])
             # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
+            nsplit = self._short_layer_split(F, (Tin + 1) // 2, B)
+            if nsplit > 1:
+                ws['dX'][i - 1].zero_()        # both parity launches add their K slices into it (split_k < 0)
             for p in (0, 1):
                 j0 = (p + pl) % 2
                 js = list(range(j0, 5, 2))
                 K.conv_gemm(x0=dX, w=Tt['enc_w'][i - 1][j0:], w_tap_stride=2 * F * F, out0=ws['dX'][i - 1], B=B,
                             T_in=Ti, T_out=(Tin - p + 1) // 2, M=F, C0=F, taps=[(p + pl - j) // 2 for j in js],
-                            out_tstride=2, out_toffset=p, T_store=Tin)
+                            out_tstride=2, out_toffset=p, T_store=Tin, tile=12 if nsplit > 1 else 0,
+                            split_k=-nsplit if nsplit > 1 else 0)
         dsc.addcmul_(self.bn_mean, G['bn_beta'], value=-1.0)         # shift = beta - mean*scale
         torch.mul(dsc, torch.rsqrt(self.bn_var + BN_EPS), out=dsc)
         G['bn_gamma'] += dsc
