@@ -162,6 +162,38 @@ def test_causal_conv_fwd_matches_oracle(K, B, T, Cin, Cout, k, dil, tile):
     close(btc(out), want, what='conv fwd')
 
 
+def _ragged_cases():
+    """Seeded random shapes for the conv engine: ragged T (partial tiles, 4-byte-aligned-only rows), every tile,
+    tail tiles forced on, split-K forced on, dilations that put taps outside the signal, odd batch sizes."""
+    rng = np.random.RandomState(2026)
+    cases = []
+    for i in range(28):
+        B = int(rng.choice([1, 2, 3, 5]))
+        T = int(rng.choice([64, 100, 128, 200, 260, 384, 500, 777, 1024, 1500]))
+        Cin = 16 * int(rng.randint(1, 7))
+        Cout = 4 * int(rng.randint(1, 80))
+        k = int(rng.choice([1, 2, 3, 5]))
+        dil = int(rng.choice([1, 2, 3, 8, 64, 300]))
+        tile = int(rng.choice([0, 11, 12, 14, 21, 22, 24]))
+        if tile and tile % 10 > 1 and rng.rand() < 0.5:
+            tile += 10000 * int(rng.randint(1, 4))           # hand some columns to half-width tail tiles
+        split = int(rng.choice([0, 0, 1, 2, 3, 7]))
+        cases.append((B, T, Cin, Cout, k, dil, tile, split, i))
+    return cases
+
+
+@pytest.mark.parametrize('B,T,Cin,Cout,k,dil,tile,split,seed', _ragged_cases())
+def test_conv_engine_ragged_shapes(K, B, T, Cin, Cout, k, dil, tile, split, seed):
+    """wavenet_ops.py:59-90 on shapes the model never uses: the engine's paths (LDS-DMA interior blocks, register
+    pipeline at the edges, tail tiles, split-K with atomics, tile heuristic) must agree with the oracle on all."""
+    x, w, b = rnd(B, T, Cin, seed=seed), rnd(k, Cin, Cout, seed=seed + 100, s=(k * Cin) ** -0.5), rnd(Cout, seed=seed + 200)
+    want = R.conv1d_v2(x, w, b, dilations=dil)
+    out = torch.full((B, Cout, T), float('nan'), device=DEV)
+    K.conv_gemm(x0=bct(x), w=g(w), bias=g(b), out0=out, B=B, T_in=T, T_out=T, M=Cout, C0=Cin,
+                taps=[-(k - 1 - j) * dil for j in range(k)], tile=tile, split_k=split)
+    close(btc(out), want, what='conv fwd (tile %d, split %d)' % (tile, split))
+
+
 def test_named_wrappers_causal(K, pkg):
     L = pkg._lib
     B, T, Cin, Cout, k, dil = 2, 384, 32, 64, 3, 2
