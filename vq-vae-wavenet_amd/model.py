@@ -12,6 +12,7 @@ variable names and shapes.
 """
 import json
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -81,6 +82,8 @@ class VQVAE:
         self.schedule = [(int(k), float(v)) for k, v in model_cfg['learning_rate_schedule'].items()]
         self.global_step = 0
         self.grad_sync = None   # parallel.GradAllReduce when training data-parallel
+        self.overlap_wgrad = os.environ.get('VQW_OVERLAP', '1') != '0'   # decoder backward on two streams
+        self._side = None
         self._build_layout()
         self._init_params(seed)
         self._ws = {}
@@ -293,6 +296,8 @@ class VQVAE:
         # backward
         ws['dnet'] = e(B, R, T)
         ws['dpre'] = e(B, 2 * R, T)
+        ws['dnet_ring'] = [ws['dnet'], e(B, R, T), e(B, R, T)]      # ping-pong sets for the two-stream backward
+        ws['dpre_ring'] = [ws['dpre'], e(B, 2 * R, T)]
         ws['dcondenc'] = e(B, self.Mall, Tz)
         ws['dcond'] = e(B, self.Cc, Tz)
         ws['dz'] = e(B, D, Tz)
@@ -344,6 +349,11 @@ class VQVAE:
         K.conv_gemm(x0=ws['X'][5], w=P['enc_w6'], bias=P['enc_b6'], out0=ws['z_e'], save0=ws['y6'] if save else None,
                     scale=sc[6 * F:], shift=sh[6 * F:], B=B, T_in=Tz, T_out=Tz, M=D, C0=F, taps=[0])
         self._quantise(spk, ws)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     @staticmethod
     def _short_layer_split(M, T_out, B, cus=256):
@@ -455,29 +465,54 @@ class VQVAE:
         G['out_b'][:, :S] += ws['bskip']
         G['skip0_b'] += ws['bskip']
         # ---- residual stack, top layer first (wavenet.py:63-74)
-        dnet, dpre, net = ws['dnet'], ws['dpre'], ws['net']
+        net = ws['net']
         seg_l = torch.empty(B, 2 * R, Tz, device=self.dev)
+        # Two streams: the chain gate-backward -> input gradient -> next layer stays on the current stream, the
+        # weight gradients and bias/condition sums of a layer (which nothing downstream waits for) run on a side
+        # stream, so one kernel's thin last round is filled by the other's blocks.  dnet / dpre are rings (3 / 2
+        # buffers): the chain may run two layers ahead of the side stream before it has to wait for it.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else main
+        dnet_ring, dpre_ring = ws['dnet_ring'], ws['dpre_ring']
+        side_done = {}
+        dnet = dnet_ring[(L - 1) % 3]
         for l in range(L - 1, -1, -1):
             d = self.dil[l]
             top = (l == L - 1)       # net[L] is unused by the graph: its gradient is zero
+            dpre = dpre_ring[l % 2]
+            dnet_next = dnet_ring[(l - 1) % 3]
+            if side is not main and (l + 2) in side_done:
+                main.wait_event(side_done[l + 2])            # dpre[l % 2] and dnet[(l - 1) % 3] are free again
             K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
                         aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
                         epilogue=K.EPI_GATE_BWD, tile=self.tiles['gate_bwd'])
-            K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
-                         Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
-            if not top:
-                K.rowsum(dnet, total=G['out_b'][l][S:])
+            if side is not main:
+                ready = torch.cuda.Event()
+                ready.record(main)
             taps_b = [(ks - 1 - j) * d for j in range(ks)]
             if top:
-                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
+                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
                             tile=self.tiles['dgrad'])
             else:
-                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T,
+                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out1=dnet_next, aux1=dnet, out0=dnet_next, B=B, T_in=T, T_out=T,
                             M=R, M0=0, C0=2 * R, taps=taps_b, epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['dgrad'])
-            K.wgrad_gemm(p=net[l], q0=dpre, dw=G['gated_w'][l], B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
-                         taps=[-(ks - 1 - j) * d for j in range(ks)])
-            K.rowsum(dpre, seg_out=seg_l, total=G['gated_b'][l], seg=ratio)
-            dce[:, l * 2 * R:(l + 1) * 2 * R].copy_(seg_l)
+            with torch.cuda.stream(side):
+                if side is not main:
+                    side.wait_event(ready)
+                K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
+                             Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
+                if not top:
+                    K.rowsum(dnet, total=G['out_b'][l][S:])
+                K.wgrad_gemm(p=net[l], q0=dpre, dw=G['gated_w'][l], B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
+                             taps=[-(ks - 1 - j) * d for j in range(ks)])
+                K.rowsum(dpre, seg_out=seg_l, total=G['gated_b'][l], seg=ratio)
+                dce[:, l * 2 * R:(l + 1) * 2 * R].copy_(seg_l)
+                if side is not main:
+                    side_done[l] = torch.cuda.Event()
+                    side_done[l].record(side)
+            dnet = dnet_next
+        if side is not main:
+            main.wait_stream(side)
         # ---- skip start + preprocess (wavenet.py:42-55)
         K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
                     C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
@@ -509,20 +544,30 @@ class VQVAE:
         K.wgrad_gemm(p=ws['X'][5], q0=dz, dw=G['enc_w6'], B=B, T_q=Tz, T_p=Tz, Cp=F, Q0=D, taps=[0])
         K.rowsum(dz, total=G['enc_b6'])
         K.conv_gemm(x0=dz, w=Tt['enc_w6'], out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else main
         for i in range(5, -1, -1):
             dX, r = ws['dX'][i], ws['r'][i]
             Ti = ws['Tl'][i]
             K.rowsum(dX, y=r, total=dsc[i * F:(i + 1) * F])
             K.rowsum(dX, total=G['bn_beta'][i * F:(i + 1) * F])
             K.bn_relu_bwd(dX, r, sc[i * F:(i + 1) * F], dX)          # dX := d(conv_i output)
-            K.rowsum(dX, total=G['enc_b'][i])
             Tin = ws['Tl'][i - 1] if i > 0 else T
             pl, _ = same_pads(Tin, 5, 2)
+            if side is not main:
+                ready = torch.cuda.Event()
+                ready.record(main)
+            with torch.cuda.stream(side):                            # weight / bias gradients: nothing downstream waits
+                if side is not main:
+                    side.wait_event(ready)
+                K.rowsum(dX, total=G['enc_b'][i])
+                if i == 0:
+                    K.conv_cin1_wgrad(x, dX, G['enc_w0'], k=5, stride=2, offset=-pl)
+                else:
+                    K.wgrad_gemm(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], B=B, T_q=Ti, T_p=Tin, Cp=F, Q0=F, p_stride=2,
+                                 taps=[j - pl for j in range(5)])
             if i == 0:
-                K.conv_cin1_wgrad(x, dX, G['enc_w0'], k=5, stride=2, offset=-pl)
                 break
-            K.wgrad_gemm(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], B=B, T_q=Ti, T_p=Tin, Cp=F, Q0=F, p_stride=2,
-                         taps=[j - pl for j in range(5)])
             # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
             nsplit = self._short_layer_split(F, (Tin + 1) // 2, B)
             if nsplit > 1:
@@ -534,6 +579,8 @@ class VQVAE:
                             T_in=Ti, T_out=(Tin - p + 1) // 2, M=F, C0=F, taps=[(p + pl - j) // 2 for j in js],
                             out_tstride=2, out_toffset=p, T_store=Tin, tile=12 if nsplit > 1 else 0,
                             split_k=-nsplit if nsplit > 1 else 0)
+        if side is not main:
+            main.wait_stream(side)
         dsc.addcmul_(self.bn_mean, G['bn_beta'], value=-1.0)         # shift = beta - mean*scale
         torch.mul(dsc, torch.rsqrt(self.bn_var + BN_EPS), out=dsc)
         G['bn_gamma'] += dsc
