@@ -145,6 +145,8 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--length', type=int, default=6656)
     ap.add_argument('--gen-steps', type=int, default=1024, help='AR samples to generate for the generation rate')
+    ap.add_argument('--encoder', default=None, help="override model_parameters.json's encoder ('64', 'Magenta', '2019'); "
+                    "'2019' needs --length 6400 (T %% 320 == 0): BASELINE.json configs[4] in fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 code path)")
@@ -170,6 +172,8 @@ def main():
     pkg = importlib.import_module('vq-vae-wavenet_amd')
     K = pkg.kernels
     m, w = default_configs()
+    if a.encoder:
+        m['encoder'] = a.encoder
     S = 109
     model = pkg.model.VQVAE(m, w, S, device=dev, seed=0)           # identical weights on every rank
     B, T = a.batch, a.length
@@ -248,8 +252,8 @@ def main():
             "unit": "audio-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VCTK '64' encoder, len=%d batch=%d per GPU, fp32, full train step "
-                                   "(fwd+bwd+allreduce+Adam+EMA)" % (T, B),
+            "config": {"workload": "VCTK '%s' encoder, len=%d batch=%d per GPU, fp32, full train step "
+                                   "(fwd+bwd+allreduce+Adam+EMA)" % (m['encoder'], T, B),
                        "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
             "loss": loss,
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<2,2,GATE> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; LDS-DMA pipeline, half-width tail tiles)",
