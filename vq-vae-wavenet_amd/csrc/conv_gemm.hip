@@ -513,25 +513,40 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
         for (int f = 0; f < NT; ++f) tz[f] = min(tb + f, d.T_out - 1) / a.ratio;
     }
 
+    float addf[4][NT], addg[4][NT];   // GATE: bias + condition of the current group of four rows
+    float oldv[4][MT][NT], oldb[4][MT];   // ACCUM_SPLIT: old output values + bias of the group
+    (void)addf; (void)addg; (void)oldv; (void)oldb;
 #pragma unroll
     for (int rho = 0; rho < 16; ++rho) {
         const int r = (rho & 3) + 8 * (rho >> 2) + 4 * lhi;  // row inside the 32x32 tile
         if constexpr (EPI == VQW_EPI_GATE) {
+            // bias and condition of FOUR rows are requested together, without a branch in between (absent operands
+            // read a valid dummy address and are masked by a select): with per-row conditionals hipcc waited
+            // vmcnt(0) three times per row, 48 dependent round trips per tile
+            if ((rho & 3) == 0) {
+                const bool hb = d.bias != nullptr, hc = d.cond_T > 0;
+                const float* bp = hb ? d.bias : d.w;
+                const float* cb = hc ? d.cond + (size_t)b * d.cond_bstride : d.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gi = min(o0 + wm * 32 + r + i, a.H - 1);
+                    const float bf = bp[hb ? gi : 0], bg = bp[hb ? a.H + gi : 0];
+#pragma unroll
+                    for (int f = 0; f < NT; ++f) {
+                        const float cf = cb[hc ? (size_t)gi * d.cond_T + tz[f] : 0];
+                        const float cg = cb[hc ? (size_t)(a.H + gi) * d.cond_T + tz[f] : 0];
+                        addf[i][f] = (hb ? bf : 0.0f) + (hc ? cf : 0.0f);
+                        addg[i][f] = (hb ? bg : 0.0f) + (hc ? cg : 0.0f);
+                    }
+                }
+            }
             const int g = o0 + wm * 32 + r;  // gated channel
             if (g < a.H) {
-                const float bfv = d.bias ? d.bias[g] : 0.0f;
-                const float bgv = d.bias ? d.bias[a.H + g] : 0.0f;
                 float og[NT], ot[NT], os[NT];
 #pragma unroll
                 for (int f = 0; f < NT; ++f) {
-                    float vf = acc[0][f][rho] + bfv, vg = acc[1][f][rho] + bgv;
-                    if (d.cond_T > 0) {
-                        const float* cb = d.cond + (size_t)b * d.cond_bstride;
-                        vf += cb[(size_t)g * d.cond_T + tz[f]];
-                        vg += cb[(size_t)(a.H + g) * d.cond_T + tz[f]];
-                    }
-                    ot[f] = tanh_f(vf);
-                    os[f] = sigmoid_f(vg);
+                    ot[f] = tanh_f(acc[0][f][rho] + addf[rho & 3][f]);
+                    os[f] = sigmoid_f(acc[1][f][rho] + addg[rho & 3][f]);
                     og[f] = ot[f] * os[f];
                 }
                 const size_t ro = ((size_t)b * a.H + g) * Ts;
@@ -540,6 +555,25 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
                 if (d.save1) store_row<NT>(d.save1 + ro, tb, d.T_out, tstr, toff, vok, os);
             }
         } else {
+            if constexpr (EPI == VQW_EPI_ACCUM_SPLIT) {
+                // the old values and biases of FOUR rows are requested together (the loads of a row otherwise wait
+                // behind the previous row's store to the same tensor)
+                if ((rho & 3) == 0) {
+                    const bool hb = d.bias != nullptr;
+                    const float* bp = hb ? d.bias : d.w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < MT; ++e) {
+                            const int rw = min(o0 + wm * (MT * 32) + MT * (r + i) + e, d.M - 1);
+                            const float* src = (rw < d.M0) ? d.out0 + ((size_t)b * d.M0 + rw) * Ts
+                                                           : d.aux1 + ((size_t)b * (d.M - d.M0) + (rw - d.M0)) * Ts;
+                            load_row<NT>(src, tb, d.T_out, tstr, toff, vok, oldv[i][e]);
+                            const float bv = bp[hb ? rw : 0];
+                            oldb[i][e] = hb ? bv : 0.0f;
+                        }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < MT; ++e) {
                 const int row = o0 + wm * (MT * 32) + MT * r + e;
@@ -584,19 +618,10 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
                                      : d.out1 + ((size_t)b * (d.M - d.M0) + (row - d.M0)) * Ts;
                     store_row<NT>(dst, tb, d.T_out, tstr, toff, vok, v);
                 } else if constexpr (EPI == VQW_EPI_ACCUM_SPLIT) {
-                    const float bv = d.bias ? d.bias[row] : 0.0f;
-                    float old[NT];
-                    float* dst;
-                    if (row < d.M0) {
-                        dst = d.out0 + ((size_t)b * d.M0 + row) * Ts;
-                        load_row<NT>(dst, tb, d.T_out, tstr, toff, vok, old);
-                    } else {
-                        const size_t ro = ((size_t)b * (d.M - d.M0) + (row - d.M0)) * Ts;
-                        dst = d.out1 + ro;
-                        load_row<NT>(d.aux1 + ro, tb, d.T_out, tstr, toff, vok, old);
-                    }
+                    float* dst = (row < d.M0) ? d.out0 + ((size_t)b * d.M0 + row) * Ts
+                                              : d.out1 + ((size_t)b * (d.M - d.M0) + (row - d.M0)) * Ts;
 #pragma unroll
-                    for (int f = 0; f < NT; ++f) v[f] = old[f] + (v[f] + bv);
+                    for (int f = 0; f < NT; ++f) v[f] = oldv[rho & 3][e][f] + (v[f] + oldb[rho & 3][e]);
                     store_row<NT>(dst, tb, d.T_out, tstr, toff, vok, v);
                 } else if constexpr (EPI == VQW_EPI_GATE_BWD) {
                     const size_t ri = ((size_t)b * a.H + row) * Ts;
