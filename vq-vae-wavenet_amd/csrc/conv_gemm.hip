@@ -514,8 +514,9 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
     }
 
     float addf[4][NT], addg[4][NT];   // GATE: bias + condition of the current group of four rows
-    float oldv[4][MT][NT], oldb[4][MT];   // ACCUM_SPLIT: old output values + bias of the group
-    (void)addf; (void)addg; (void)oldv; (void)oldb;
+    float oldv[4][MT][NT], oldb[4][MT];   // ACCUM_SPLIT: old output values + bias of the group (GATE_BWD: saved tanh)
+    float oldw[4][MT][NT];                // GATE_BWD: saved sigmoid
+    (void)addf; (void)addg; (void)oldv; (void)oldb; (void)oldw;
 #pragma unroll
     for (int rho = 0; rho < 16; ++rho) {
         const int r = (rho & 3) + 8 * (rho >> 2) + 4 * lhi;  // row inside the 32x32 tile
@@ -555,6 +556,19 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
                 if (d.save1) store_row<NT>(d.save1 + ro, tb, d.T_out, tstr, toff, vok, os);
             }
         } else {
+            if constexpr (EPI == VQW_EPI_GATE_BWD) {
+                if ((rho & 3) == 0) {   // saved tanh / sigmoid of four rows at once
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < MT; ++e) {
+                            const int rw = min(o0 + wm * (MT * 32) + MT * (r + i) + e, d.M - 1);
+                            const size_t ri = ((size_t)b * a.H + rw) * Ts;
+                            load_row<NT>(d.aux0 + ri, tb, d.T_out, tstr, toff, vok, oldv[i][e]);
+                            load_row<NT>(d.aux1 + ri, tb, d.T_out, tstr, toff, vok, oldw[i][e]);
+                        }
+                }
+            }
             if constexpr (EPI == VQW_EPI_ACCUM_SPLIT) {
                 // the old values and biases of FOUR rows are requested together (the loads of a row otherwise wait
                 // behind the previous row's store to the same tensor)
@@ -624,14 +638,12 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
                     for (int f = 0; f < NT; ++f) v[f] = oldv[rho & 3][e][f] + (v[f] + oldb[rho & 3][e]);
                     store_row<NT>(dst, tb, d.T_out, tstr, toff, vok, v);
                 } else if constexpr (EPI == VQW_EPI_GATE_BWD) {
-                    const size_t ri = ((size_t)b * a.H + row) * Ts;
-                    float th[NT], sg[NT], o1[NT], o2[NT];
-                    load_row<NT>(d.aux0 + ri, tb, d.T_out, tstr, toff, vok, th);
-                    load_row<NT>(d.aux1 + ri, tb, d.T_out, tstr, toff, vok, sg);
+                    float o1[NT], o2[NT];
 #pragma unroll
                     for (int f = 0; f < NT; ++f) {
-                        o1[f] = v[f] * sg[f] * (1.0f - th[f] * th[f]);
-                        o2[f] = v[f] * th[f] * sg[f] * (1.0f - sg[f]);
+                        const float th = oldv[rho & 3][e][f], sg = oldw[rho & 3][e][f];
+                        o1[f] = v[f] * sg * (1.0f - th * th);
+                        o2[f] = v[f] * th * sg * (1.0f - sg);
                     }
                     store_row<NT>(d.out0 + ((size_t)b * 2 * a.H + row) * Ts, tb, d.T_out, tstr,
                                   toff, vok, o1);
