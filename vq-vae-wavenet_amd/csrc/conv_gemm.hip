@@ -508,10 +508,8 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
     const int tstr = d.out_tstride, toff = d.out_toffset, vok = a.vec_ok;
 
     int tz[NT];
-    if (d.cond_T > 0) {
 #pragma unroll
-        for (int f = 0; f < NT; ++f) tz[f] = min(tb + f, d.T_out - 1) / a.ratio;
-    }
+    for (int f = 0; f < NT; ++f) tz[f] = (d.cond_T > 0) ? min(tb + f, d.T_out - 1) / a.ratio : 0;
 
     float addf[4][NT], addg[4][NT];   // GATE: bias + condition of the current group of four rows
     float oldv[4][MT][NT], oldb[4][MT];   // ACCUM_SPLIT: old output values + bias of the group (GATE_BWD: saved tanh)
@@ -556,6 +554,30 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
                 if (d.save1) store_row<NT>(d.save1 + ro, tb, d.T_out, tstr, toff, vok, os);
             }
         } else {
+            if constexpr (EPI == VQW_EPI_STORE) {
+                if ((rho & 3) == 0 && a.ksplit <= 1) {   // bias, condition, BN affine of four rows at once, branch-free
+                    const bool hb = d.bias != nullptr, hc = d.cond_T > 0, hs = d.scale != nullptr;
+                    const float* bp = hb ? d.bias : d.w;
+                    const float* cb = hc ? d.cond + (size_t)b * d.cond_bstride : d.w;
+                    const float* sp = hs ? d.scale : d.w;
+                    const float* hp = hs ? d.shift : d.w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < MT; ++e) {
+                            const int rw = min(o0 + wm * (MT * 32) + MT * (r + i) + e, d.M - 1);
+                            const float bv = bp[hb ? rw : 0];
+                            oldb[i][e] = hb ? bv : 0.0f;
+#pragma unroll
+                            for (int f = 0; f < NT; ++f) {
+                                const float cv = cb[hc ? (size_t)rw * d.cond_T + tz[f] : 0];
+                                oldv[i][e][f] = hc ? cv : 0.0f;
+                            }
+                            oldw[i][e][0] = sp[hs ? rw : 0];
+                            if (NT > 1) oldw[i][e][1] = hp[hs ? rw : 0];
+                        }
+                }
+            }
             if constexpr (EPI == VQW_EPI_GATE_BWD) {
                 if ((rho & 3) == 0) {   // saved tanh / sigmoid of four rows at once
 #pragma unroll
@@ -605,21 +627,18 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
                             if (tb + f < d.T_out) unsafeAtomicAdd(dst + tstr * (tb + f) + toff, v[f] + bv0);
                         continue;
                     }
-                    const float bv = d.bias ? d.bias[row] : 0.0f;
 #pragma unroll
                     for (int f = 0; f < NT; ++f) {
-                        v[f] += bv;
-                        if (d.cond_T > 0)
-                            v[f] += d.cond[(size_t)b * d.cond_bstride + (size_t)row * d.cond_T + tz[f]];
+                        v[f] = (v[f] + oldb[rho & 3][e]) + oldv[rho & 3][e][f];     // + bias, + condition
                         if (d.out_relu) v[f] = fmaxf(v[f], 0.0f);
                     }
                     if (d.save0)
                         store_row<NT>(d.save0 + ((size_t)b * d.M + row) * Ts, tb, d.T_out, tstr,
                                       toff, vok, v);
                     if (d.scale) {
-                        const float sc = d.scale[row], sh = d.shift[row];
+                        const float sc = oldw[rho & 3][e][0], sh = oldw[rho & 3][e][NT > 1 ? 1 : 0];
 #pragma unroll
-                        for (int f = 0; f < NT; ++f) v[f] = sc * v[f] + sh;
+                        for (int f = 0; f < NT; ++f) v[f] = sc * v[f] + (NT > 1 ? sh : d.shift[row]);
                     }
                     if (d.aux1) {   // residual added after the activation: net = act(conv) + net
                         float res[NT];
