@@ -60,11 +60,11 @@ for d in (1, 512):
                         2.0 * N * 3 * R * 2 * R)
         print('dgrad      d=%-3d tile=%d  %.3f ms  %.1f TF/s' % (d, tile, ms, tf), flush=True)
 for d in (1, 512):
-    for splits in (0, 2, 4, 8):
+    for splits in (0, 5, 6, 7, 8, 10, 13):
         ms, tf = timeit(lambda: K.wgrad_gemm(p=net, q0=dpre, dw=dwg, B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
                                              taps=[-2 * d, -d, 0], splits=splits), 2.0 * N * 3 * R * 2 * R)
         print('wgrad gate d=%-3d splits=%d  %.3f ms  %.1f TF/s' % (d, splits, ms, tf), flush=True)
-for splits in (0, 4, 8, 13):
+for splits in (0, 6, 7, 8, 9, 10, 11, 12, 16):
     ms, tf = timeit(lambda: K.wgrad_gemm(p=gated, q0=skip, q1=net2, dw=dwo, B=B, T_q=T, T_p=T, Cp=R, Q0=S, Q1=R, lddw=S + R,
                                          taps=[0], splits=splits), 2.0 * N * R * (S + R))
     print('wgrad out  splits=%d  %.3f ms  %.1f TF/s' % (splits, ms, tf), flush=True)

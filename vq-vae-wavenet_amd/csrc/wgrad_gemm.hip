@@ -287,6 +287,13 @@ extern "C" int vqw_wgrad_gemm(const vqw_wgrad_desc* dp, vqw_stream_t s) {
         // aim for ~6 blocks per CU over the whole chip (measured best on MI355X: bench_kernels.py)
         chunks = vqw_cdiv(1536, tiles * d.B);
         const int max_chunks = vqw_cdiv(d.T_q, 4 * BT);
+        // ... but keep >= 24 K-steps per block while that still gives two blocks per CU: the 1x1 skip|residual
+        // kernel gradient (12 tiles) ran 102 TFLOP/s with 16 chunks of 13 K-steps, 111 with 8 chunks of 26
+        const int by_len = d.T_q / (24 * BT) > 1 ? d.T_q / (24 * BT) : 1;
+        if (chunks > by_len) {
+            chunks = by_len;
+            if ((long)tiles * d.B * chunks < 512) chunks = vqw_cdiv(512, tiles * d.B);
+        }
         if (chunks > max_chunks) chunks = max_chunks;
         if (chunks < 1) chunks = 1;
     }
