@@ -137,6 +137,26 @@ def cpu_baseline(B, T, steps):
                       "after 1 warm-up step" % (steps, B, T), "ms_per_step": dt * 1e3}
 
 
+def cpu_ar_baseline(steps):
+    """The oracle's FIFO-queue generator (wavenet_ops.py:147-267 restated in torch-CPU fp32) timed on the host
+    cores: greedy samples/s of one utterance at the default widths."""
+    from oracle import ref_model as M
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    P = M.init_params(m, w, 109, seed=0)
+    g = M.FastGenerator(P, w, 1)
+    cond = torch.zeros(1, m['latent_dim'] + m['speaker_embedding'])
+    a = torch.zeros(1, 1)
+    with torch.no_grad():
+        g.step(a, cond)                                  # warm-up
+        t0 = time.time()
+        for _ in range(steps):
+            pr = g.step(a, cond)
+            a = torch.from_numpy(M.R.mu_law_decode_np(pr.argmax(-1).numpy().astype('float32'))).reshape(1, 1)
+        dt = time.time() - t0
+    return {"value": steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d greedy steps of the torch-CPU oracle generator, batch 1" % steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -144,7 +164,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--length', type=int, default=6656)
-    ap.add_argument('--gen-steps', type=int, default=1024, help='AR samples to generate for the generation rate')
+    ap.add_argument('--gen-steps', type=int, default=8192, help='AR samples to generate for the generation rate (SURVEY 8(d): L >= 8192)')
     ap.add_argument('--encoder', default=None, help="override model_parameters.json's encoder ('64', 'Magenta', '2019'); "
                     "'2019' needs --length 6400 (T %% 320 == 0): BASELINE.json configs[4] in fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -266,6 +286,8 @@ def main():
             rec["ar_gen"] = gen
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(1, T, 12)          # ~10 s of host work
+            if gen:
+                rec["ar_gen"]["cpu_baseline"] = cpu_ar_baseline(128)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
