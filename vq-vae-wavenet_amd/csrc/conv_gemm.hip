@@ -33,6 +33,10 @@ namespace {
 #define VQW_SCHED 1
 #endif
 constexpr int BK = VQW_BK;  // channels per K-step
+#ifndef VQW_NST
+#define VQW_NST 3
+#endif
+constexpr int NST_DMA = VQW_NST;   // LDS stages of the LDS-DMA pipeline (experiment: 2 = one more block per CU)
 #if VQW_SCHED
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -429,7 +433,7 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
 #pragma unroll
         for (int q = 0; q < NDMA; ++q) dma(q, 0);
         advance();
-        if (nsteps > 1) {
+        if (NST_DMA == 3 && nsteps > 1) {
 #pragma unroll
             for (int q = 0; q < NDMA; ++q) dma(q, 1);
             advance();
@@ -469,21 +473,30 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
             }
             if constexpr (MODE == 1) {
                 advance();
-                __builtin_amdgcn_s_waitcnt(WAIT_NEXT);   // my pieces of tile s+1 have landed; tile s+2 stays in flight
+                if constexpr (NST_DMA == 3) __builtin_amdgcn_s_waitcnt(WAIT_NEXT);   // my pieces of tile s+1 have landed; tile s+2 stays in flight
+                else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
             } else {
                 __builtin_amdgcn_s_waitcnt(WAIT_ALL);
             }
             __builtin_amdgcn_s_barrier();                // everybody's pieces of tile s+1 have landed; stage cur is free
         };
         int s = 0, cur = 0;
-        for (; s + 2 < nsteps; ++s) {
-            const int nxt = (cur == 0) ? 2 : cur - 1;    // (cur + 2) % 3
-            kstep(std::integral_constant<int, 1>{}, cur, nxt);
-            cur = (cur == 2) ? 0 : cur + 1;
-        }
-        for (; s < nsteps; ++s) {
-            kstep(std::integral_constant<int, 0>{}, cur, 0);
-            cur = (cur == 2) ? 0 : cur + 1;
+        if constexpr (NST_DMA == 3) {
+            for (; s + 2 < nsteps; ++s) {
+                const int nxt = (cur == 0) ? 2 : cur - 1;    // (cur + 2) % 3
+                kstep(std::integral_constant<int, 1>{}, cur, nxt);
+                cur = (cur == 2) ? 0 : cur + 1;
+            }
+            for (; s < nsteps; ++s) {
+                kstep(std::integral_constant<int, 0>{}, cur, 0);
+                cur = (cur == 2) ? 0 : cur + 1;
+            }
+        } else {   // two stages: tile s+1 travels while tile s is multiplied, nothing in flight across the barrier
+            for (; s + 1 < nsteps; ++s) {
+                kstep(std::integral_constant<int, 1>{}, cur, cur ^ 1);
+                cur ^= 1;
+            }
+            if (s < nsteps) kstep(std::integral_constant<int, 0>{}, cur, 0);
         }
     };
     bool all_interior = true;
@@ -687,8 +700,8 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, float* const smem,
 // blocks (B*T = 13*2^12 makes every tiling a multiple of 13 blocks).  ONE LDS array, sized for the main tile
 // (a second __shared__ object beside LDS-DMA traffic makes hipcc drain vmcnt before every ds_read).
 template <int MT, int NT, int EPI>
-__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? 3 : 4)) void conv_gemm_kernel(const ConvArgs a) {
-    constexpr int NST = 3;
+__global__ __launch_bounds__(256, (MT * NT >= 8) ? 2 : ((MT * NT >= 4) ? (NST_DMA == 2 ? 4 : 3) : 4)) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int NST = NST_DMA;
     __shared__ __attribute__((aligned(16))) float smem[NST * BK * 64 * (MT + NT)];
     int bid = blockIdx.x, ks = 0;
     if (a.ksplit > 1) {
@@ -864,7 +877,7 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
     const int mtm = main_tile / 10, ntm = main_tile % 10;
     if (mtm < 1 || mtm > 2 || (ntm != 1 && ntm != 2 && ntm != 4)) return vqw_set_error("vqw_conv_gemm: unsupported tile %d", tile);
     if (tile < 10000 && tail_env && ntm > 1) {
-        const int occ = (main_tile == 22) ? 3 : (main_tile == 24 || main_tile == 14) ? 2 : 4;
+        const int occ = (main_tile == 22) ? (NST_DMA == 2 ? 4 : 3) : (main_tile == 24 || main_tile == 14) ? 2 : 4;
         const int n_mt = (d.epilogue == VQW_EPI_GATE) ? vqw_cdiv(a.H, 32 * mtm) : vqw_cdiv(d.M, 64 * mtm);
         const long slots = (long)cus * occ, per_col = (long)n_mt * d.B, nblk = per_col * vqw_cdiv(d.T_out, 64 * ntm);
         const long rem = nblk % slots;
