@@ -389,6 +389,34 @@ def test_wgrad_two_sources_relu_and_full_size(K):
     close(dw, wz.grad, rtol=1e-3, atol=1e-3, what='wgrad full size')
 
 
+def _wgrad_ragged_cases():
+    rng = np.random.RandomState(77)
+    cases = []
+    for i in range(16):
+        B = int(rng.choice([1, 2, 3]))
+        T = int(rng.choice([96, 160, 333, 512, 1000, 2080]))
+        Cp = 16 * int(rng.randint(1, 12))
+        Q = 4 * int(rng.randint(1, 70))
+        k = int(rng.choice([1, 2, 3]))
+        dil = int(rng.choice([1, 2, 5, 64]))
+        splits = int(rng.choice([0, 0, 1, 2, 5]))
+        cases.append((B, T, Cp, Q, k, dil, splits, i))
+    return cases
+
+
+@pytest.mark.parametrize('B,T,Cp,Q,k,dil,splits,seed', _wgrad_ragged_cases())
+def test_wgrad_engine_ragged_shapes(K, B, T, Cp, Q, k, dil, splits, seed):
+    """Conv2DBackpropFilter of wavenet_ops.py:59-90 on shapes the model never uses (ragged T, partial tiles, any
+    split count incl. the automatic one) against autograd of the oracle's conv1d_v2."""
+    x, dy = rnd(B, T, Cp, seed=seed), rnd(B, T, Q, seed=seed + 50)
+    wz = torch.zeros(k, Cp, Q, requires_grad=True)
+    R.conv1d_v2(x, wz, None, dilations=dil).backward(dy)
+    dw = torch.zeros(k, Cp, Q, device=DEV)
+    K.wgrad_gemm(p=bct(x), q0=bct(dy), dw=dw, B=B, T_q=T, T_p=T, Cp=Cp, Q0=Q, taps=[-(k - 1 - j) * dil for j in range(k)],
+                 splits=splits)
+    close(dw, wz.grad, rtol=1e-3, atol=1e-3, what='wgrad (splits %d)' % splits)
+
+
 # ----------------------------------------------------------------------------- small kernels
 def test_conv_cin1_fwd_and_wgrad(K):
     B, T, F, k = 2, 520, 32, 32
