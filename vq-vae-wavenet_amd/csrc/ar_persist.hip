@@ -42,7 +42,17 @@ typedef unsigned long long u64;
 constexpr int PB = 4;        // max batch rows of one persistent launch (LDS budget; larger batches: several handles)
 constexpr int PJ = 8;        // max Q / R
 constexpr int NCT = 256;     // compute threads (waves 0-3)
-constexpr int NGL = 128;     // lanes of the fresh role (waves 4-5) and of the history role (waves 6-7)
+#ifndef ARP_NGF
+#define ARP_NGF 128
+#endif
+#ifndef ARP_NGH
+#define ARP_NGH 128
+#endif
+// Role split measured on the reference stack (us per sample, 1 / 2 / 4 rows): fresh 128 lanes 67 / 100 / 127;
+// 256 lanes (9 waves, one granule per lane and segment) 101 / 119 / -; 64 lanes 87 / 97 / 146.
+constexpr int NGF = ARP_NGF;           // lanes of the fresh role (the waves after the 4 compute waves)
+constexpr int NGH = ARP_NGH;           // lanes of the history role (the last waves)
+constexpr int NTHR = 256 + NGF + NGH;   // threads of a workgroup
 constexpr unsigned long long TIMEOUT_TICKS = 300000000ull;  // 3 s of s_memrealtime (100 MHz)
 
 struct PArgs {
@@ -65,7 +75,7 @@ struct PArgs {
     int* indices;
     float* probs_last;
 #ifdef VQW_AR_TRACE
-    u64* trace;                   // [gridDim][8 waves][16] accumulated s_memrealtime ticks (tools/ar_trace.py)
+    u64* trace;                   // [gridDim][16 waves][16] accumulated s_memrealtime ticks (tools/ar_trace.py)
 #endif
 };
 
@@ -295,7 +305,7 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
 #ifdef VQW_AR_TRACE
 #define TR_DECL u64 tr_acc[16] = {0}; u64 tr_t = __builtin_amdgcn_s_memrealtime();
 #define TR(i) { const u64 n_ = __builtin_amdgcn_s_memrealtime(); tr_acc[i] += n_ - tr_t; tr_t = n_; }
-#define TR_DUMP if (a.trace && (tid & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) a.trace[((size_t)bi * 8 + (tid >> 6)) * 16 + i_] = tr_acc[i_];
+#define TR_DUMP if (a.trace && (tid & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) a.trace[((size_t)bi * 16 + (tid >> 6)) * 16 + i_] = tr_acc[i_];
 #else
 #define TR_DECL
 #define TR(i)
@@ -307,7 +317,7 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
 // (Compile-time load counts let the compiler wait with exact vmcnt values: with a run-time count it falls back to
 // vmcnt(0) in front of the first use, i.e. waits for the loads it has requested a moment earlier.)
 template <int TB, int RLT, int NS, int KS, int CPB>
-__global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
+__global__ __launch_bounds__(NTHR, 1) void ar_persist_kernel(const PArgs a) {
     extern __shared__ float lds[];
     constexpr int LPC = NCT / CPB;                        // lanes per channel
     constexpr int PUBL = LPC - 1;                         // the lane that ends up with a channel's sums and publishes them
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
     constexpr int NPW = ((KS - 1) * RLT * 2 + 3) / 4;     // float4 groups per thread: past taps
     constexpr int NCW = (RLT * NCOL + 3) / 4;             // float4 groups per thread: critical columns
     const int bi = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
-    const int role = tid >> 8 ? (tid >> 7) - 1 : 0;       // 0 compute (tid < 256), 1 fresh (256..383), 2 history (384..511)
+    const int role = tid < NCT ? 0 : (tid < NCT + NGF ? 1 : 2);   // 0 compute, 1 fresh, 2 history
     const int ct = tid & (NCT - 1);
     const int cg = ct / LPC, kl = ct % LPC;
     const int c = bi * CPB + cg;                          // compute thread's channel
@@ -338,12 +348,12 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
 
     const int t0 = a.state[0];
     // ---------------- one-time LDS fill
-    for (int i = tid; i < cv.nhead * NCT; i += 512) lds[cv.hw + i] = a.headw[(size_t)bi * cv.nhead * NCT + i];
-    for (int i = tid; i < cv.nbias; i += 512) lds[cv.bias + i] = a.bias[(size_t)bi * cv.nbias + i];
-    for (int i = tid; i < L; i += 512) { tab[i] = a.dil[i]; tab[L + i] = a.ring_off[i]; }
-    for (int i = tid; i < B * a.pre_k; i += 512) xh[i] = a.xhist[i];
+    for (int i = tid; i < cv.nhead * NCT; i += NTHR) lds[cv.hw + i] = a.headw[(size_t)bi * cv.nhead * NCT + i];
+    for (int i = tid; i < cv.nbias; i += NTHR) lds[cv.bias + i] = a.bias[(size_t)bi * cv.nbias + i];
+    for (int i = tid; i < L; i += NTHR) { tab[i] = a.dil[i]; tab[L + i] = a.ring_off[i]; }
+    for (int i = tid; i < B * a.pre_k; i += NTHR) xh[i] = a.xhist[i];
     if (tid == 0) *fail = 0;
-    for (int i = tid; i <= Q; i += 512) {
+    for (int i = tid; i <= Q; i += NTHR) {
         const float dec = p_mu_dec((float)i);
         lds[cv.dtab + i] = dec;
         lds[cv.dtab + Q + 1 + i] = p_mu_enc(dec);
@@ -559,11 +569,11 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
         while (it < a.n_steps && !stop) phase();
     } else {
         // ======================================================================== gather waves
-        const int gid = tid & (NGL - 1);
+        const int gid = role == 1 ? tid - NCT : tid - NCT - NGF;
         // History role: the dilation-queue taps of global phase Pq (old news, but ~1.2 us of load latency each) are
         // requested in one phase and committed to xpast[Pq % 3] in the next one, so that the loads are in flight
         // across the phase barrier instead of holding it up (a raw s_barrier does not drain vmcnt).
-        constexpr int HMAX = PB * 256 / NGL;               // granules per lane and tap (B <= PB, R <= 256)
+        constexpr int HMAX = PB * 256 / NGH;               // granules per lane and tap (B <= PB, R <= 256)
         u64 hv[KS - 1][HMAX];
         const u64* hsrc[KS - 1];
         unsigned htag[KS - 1];
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                 htag[j] = (unsigned)tau + 1u;
 #pragma unroll
                 for (int m = 0; m < HMAX; ++m) {
-                    const int idx = gid + NGL * m;
+                    const int idx = gid + NGH * m;
                     hv[j][m] = (hsrc[j] && idx < nBR) ? __hip_atomic_load(hsrc[j] + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 }
             }
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
             for (int j = 0; j < KS - 1; ++j)
 #pragma unroll
                 for (int m = 0; m < HMAX; ++m) {
-                    const int idx = gid + NGL * m;
+                    const int idx = gid + NGH * m;
                     if (idx < nBR) {
                         float x = 0.0f;
                         if (hsrc[j]) x = __uint_as_float((unsigned)poll_granule(fail, hsrc[j] + idx, htag[j], hv[j][m]));
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                     if (frame != last_frame) {   // condition projections of this frame for my 8 channels (all layers)
                         last_frame = frame;
                         const int per = CPB * B;
-                        for (int i = gid; i < (L * 2 + NS) * per; i += NGL) {
+                        for (int i = gid; i < (L * 2 + NS) * per; i += NGF) {
                             const int b = i % B, g8 = (i / B) % CPB, lh = i / per;
                             const int ch = bi * CPB + g8;
                             float v;
@@ -642,8 +652,8 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                 // nothing can arrive before the producers' critical chain + the store's travel time: polling earlier only
                 // queues requests in front of the compute waves' weight loads (measured: 84 -> 75 us per sample; 8..20 are equivalent, 1 and 28+ slower)
                 __builtin_amdgcn_s_sleep(ARP_POLL_SLEEP);
-                if (p == 0) { if (TB > 1 && B >= 3) gather_segs<1, NGL, true>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); else gather_segs<1, NGL, false>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); }
-                else { if (TB > 1 && B >= 3) gather_segs<2, NGL, true>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); else gather_segs<2, NGL, false>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); }
+                if (p == 0) { if (TB > 1 && B >= 3) gather_segs<1, NGF, true>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); else gather_segs<1, NGF, false>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); }
+                else { if (TB > 1 && B >= 3) gather_segs<2, NGF, true>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); else gather_segs<2, NGF, false>(gid, fail, src, tag, nBR, xfresh + (P & 1) * 2 * nBR, 0); }
                 TR(1)
             } else {
                 hist_commit();                             // target P+2, requested one phase ago
@@ -655,21 +665,21 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
                 if (role == 1) {
                     const u64* src[1] = {a.ex_s};
                     const unsigned tag[1] = {seq + (unsigned)L};
-                    { if (TB > 1 && B >= 3) gather_segs<1, NGL, true>(gid, fail, src, tag, B * S, hx1, 1); else gather_segs<1, NGL, false>(gid, fail, src, tag, B * S, hx1, 1); }
+                    { if (TB > 1 && B >= 3) gather_segs<1, NGF, true>(gid, fail, src, tag, B * S, hx1, 1); else gather_segs<1, NGF, false>(gid, fail, src, tag, B * S, hx1, 1); }
                 }
                 TR(3)
                 role_barrier();                            // BAR_H1
                 if (role == 1) {
                     const u64* src[1] = {a.ex_h};
                     const unsigned tag[1] = {seq + (unsigned)L + 1u};
-                    { if (TB > 1 && B >= 3) gather_segs<1, NGL, true>(gid, fail, src, tag, B * S, hx2, 1); else gather_segs<1, NGL, false>(gid, fail, src, tag, B * S, hx2, 1); }
+                    { if (TB > 1 && B >= 3) gather_segs<1, NGF, true>(gid, fail, src, tag, B * S, hx2, 1); else gather_segs<1, NGF, false>(gid, fail, src, tag, B * S, hx2, 1); }
                 }
                 TR(4)
                 role_barrier();                            // BAR_H2
                 if (role == 1) {
                     const u64* src[1] = {a.ex_l};
                     const unsigned tag[1] = {seq + (unsigned)L + 2u};
-                    { if (TB > 1 && B >= 3) gather_segs<1, NGL, true>(gid, fail, src, tag, B * Q, hx1, 0); else gather_segs<1, NGL, false>(gid, fail, src, tag, B * Q, hx1, 0); }
+                    { if (TB > 1 && B >= 3) gather_segs<1, NGF, true>(gid, fail, src, tag, B * Q, hx1, 0); else gather_segs<1, NGF, false>(gid, fail, src, tag, B * Q, hx1, 0); }
                 }
                 TR(5)
                 role_barrier();                            // BAR_H3
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(512, 1) void ar_persist_kernel(const PArgs a) {
         return;
     }
     if (bi == 0) {
-        for (int i = tid; i < B * a.pre_k; i += 512) a.xhist[i] = xh[i];
+        for (int i = tid; i < B * a.pre_k; i += NTHR) a.xhist[i] = xh[i];
         if (tid == 0) a.state[0] = t0 + a.n_steps;
     }
 }
@@ -985,12 +995,12 @@ int arp_run(ArPersist* h, const float* const* condenc, int Tz, int ratio, int n_
     a.Tz = Tz; a.ratio = ratio; a.mode = mode; a.n_steps = n_steps;
     a.uniforms = uniforms; a.audio = audio; a.indices = indices; a.probs_last = probs_last;
 #ifdef VQW_AR_TRACE
-    if (!h->trace) h->trace = (u64*)pmalloc(h, (size_t)h->nwg * 8 * 16 * sizeof(u64));
+    if (!h->trace) h->trace = (u64*)pmalloc(h, (size_t)h->nwg * 16 * 16 * sizeof(u64));
     a.trace = h->trace;
     h->trace_steps = n_steps;
 #endif
     void* params[] = {&a};
-    PHIPC(hipLaunchKernel(h->kfn, dim3(h->nwg), dim3(512), params, h->lds_bytes, st));
+    PHIPC(hipLaunchKernel(h->kfn, dim3(h->nwg), dim3(NTHR), params, h->lds_bytes, st));
     return 0;
 }
 
@@ -1000,10 +1010,10 @@ int arp_error(ArPersist* h, hipStream_t st) {
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
 #ifdef VQW_AR_TRACE
     if (h->trace && getenv("VQW_AR_TRACE_PRINT")) {
-        const int nw = h->nwg * 8;
+        const int nw = h->nwg * 16;
         std::vector<u64> t((size_t)nw * 16);
         (void)hipMemcpy(t.data(), h->trace, t.size() * sizeof(u64), hipMemcpyDeviceToHost);
-        const int picks[3] = {0, 4, 6};
+        const int picks[3] = {0, 4, 4 + NGF / 64};
         const char* names[3] = {"compute", "fresh", "history"};
         for (int k = 0; k < 3; ++k) {
             const int w = picks[k];
