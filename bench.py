@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 matrix peak, same guide (only used by the experimental VQW_GATE_F16X3=1 mode)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -66,6 +67,8 @@ class GateConvTimer:
     def __init__(self, kernels_mod):
         self.K = kernels_mod
         self.orig = kernels_mod.conv_gemm
+        self.orig_x3 = kernels_mod.f16x3_gate_conv
+        self.x3 = False          # the experimental fp16x3 gate kernel was the one launched
         self.events = []
         self.on = False
 
@@ -82,11 +85,24 @@ class GateConvTimer:
                 self.events.append((e0, e1))
             else:
                 self.orig(**kw)
+        def wrapped_x3(**kw):
+            if self.on:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.orig_x3(**kw)
+                e1.record()
+                self.events.append((e0, e1))
+                self.x3 = True
+            else:
+                self.orig_x3(**kw)
         K.conv_gemm = wrapped
+        K.f16x3_gate_conv = wrapped_x3
         return self
 
     def __exit__(self, *a):
         self.K.conv_gemm = self.orig
+        self.K.f16x3_gate_conv = self.orig_x3
 
     def mean_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
@@ -221,6 +237,7 @@ def main():
         dt = time.perf_counter() - t0
         gt.on = False
         gate_ms = gt.mean_ms()
+        gate_x3 = gt.x3
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -282,6 +299,11 @@ def main():
                          "ms_per_launch": gate_ms, "flop_per_launch": flops_gate,
                          "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
         }
+        if gate_x3:   # VQW_GATE_F16X3=1 (experimental): three fp16 MFMA terms per product, priced on the 16-bit pipe
+            rec["dtype"] = "f32 (gate convs: fp32 operands as two fp16 planes, 3 MFMA terms, fp32 accumulate)"
+            rec["roofline"].update({"kernel": "gate_f16x3_kernel (experimental; dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate on the fp16 matrix pipe)",
+                                    "achieved": 3 * ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * ach / PEAK_F16_MFMA_TFLOPS,
+                                    "fp32_equivalent_tflops": ach, "flop_per_launch": 3 * flops_gate, "traffic": None})
         if gen:
             rec["ar_gen"] = gen
         if world == 1 and not a.no_cpu_baseline:

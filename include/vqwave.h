@@ -292,6 +292,34 @@ int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding, int Tz, in
 int vqw_ar_decode_wait(vqw_ar_decoder* h);
 int vqw_ar_decode_destroy(vqw_ar_decoder* h);
 
+/* ---- EXPERIMENTAL (opt-in; the fp32-MFMA engine above stays the default path): the decoder's gate conv
+ * (wavenet_ops.py:104-114, conv1d_v2 k taps + add_condition + tanh*sigmoid) as an fp32-accurate contraction on the
+ * fp16 matrix pipe: every operand is split into two fp16 planes (x = h1 + h2), products h1 h1 + h1 h2 + h2 h1 in
+ * fp32 accumulators (DESIGN.md 3.2b for the error analysis and measurements).
+ * Plane layout: [plane 0..1][channel chunk of 8][row][8 fp16] (16-byte entries); 2 * rows * channels bytes each.    */
+
+/* x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0 */
+int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, vqw_stream_t s);
+/* w [ks][R][ldw] fp32 (kernel[k, Cin, Cout]: filter columns 0..R-1, gate columns R..2R-1), multiplied by `scale`
+ * (a power of two that lifts the residual plane into fp16's normal range, e.g. 256) -> planes [2][ks*R/8][2R][8]
+ * with the output channels in the kernel's block order; R % 128 == 0 */
+int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, vqw_stream_t s);
+
+typedef struct vqw_f16x3_gate_desc {
+    const void* xp;      /* activation planes of the layer input [B][R][T]                  */
+    const void* wp;      /* weight planes (vqw_f16x3_pack_gate_weights)                     */
+    const float* bias;   /* [2R] or NULL                                                    */
+    const float* cond;   /* projected condition [B][2R][cond_T] (batch stride cond_bstride) or NULL */
+    float* out0;         /* tanh(filter) * sigmoid(gate)  [B][R][T]                         */
+    float* save0;        /* tanh    [B][R][T] or NULL (kept for the backward pass)          */
+    float* save1;        /* sigmoid [B][R][T] or NULL                                       */
+    int64_t cond_bstride;
+    int32_t B, T, R, ks, dilation, cond_T;
+    float w_scale_inv;   /* 1 / scale of the weight planes                                  */
+} vqw_f16x3_gate_desc;
+/* T % 256 == 0, R % 128 == 0, (T / cond_T) % 32 == 0; tap j reads x[t - (ks-1-j)*dilation], zero before t = 0 */
+int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -305,6 +305,63 @@ def test_gate_conv_full_size_properties(K, d):
     assert not torch.equal(out2[:, :, t0:], out[:, :, t0:])
 
 
+@pytest.mark.parametrize('B,T,Rr,ks,d', [(2, 512, 128, 3, 1), (2, 512, 128, 2, 7), (1, 1024, 256, 3, 64),
+                                         (2, 768, 128, 3, 300), (8, 6656, 256, 3, 4), (8, 6656, 256, 3, 512)])
+def test_gate_conv_f16x3_matches_fp32_engine(K, B, T, Rr, ks, d):
+    """Experimental gate conv on the fp16 matrix pipe (two fp16 planes per operand, three MFMA terms)
+    against (1) the fp32-MFMA engine on the same inputs -- two fp32-accurate evaluations of wavenet_ops.py:104-114,
+    equal to 2e-5 over all 13.6 M outputs of the benchmark shape -- and (2) an fp64 evaluation at sampled points, where it must be at least as close as the
+    tolerance the fp32 engine is held to (2e-5).  Covers the causal zero padding (dilation beyond the tile and
+    beyond the signal), both kernel sizes of the reference configs, and the full benchmark shape."""
+    ratio = 64 if T % 64 == 0 and (T // 64) >= 1 else 32
+    Tz = T // ratio
+    gen = torch.Generator().manual_seed(1000 + d + T)
+    x = torch.randn(B, Rr, T, generator=gen)
+    w = torch.randn(ks, Rr, 2 * Rr, generator=gen) * 0.05
+    b = torch.randn(2 * Rr, generator=gen) * 0.3
+    cond = torch.randn(B, 2 * Rr, Tz, generator=gen) * 0.3
+    xd, wd, bd, cd = x.to(DEV), w.to(DEV), b.to(DEV), cond.to(DEV)
+    taps = [-(ks - 1 - j) * d for j in range(ks)]
+    ref = torch.empty(B, Rr, T, device=DEV); rth = torch.empty_like(ref); rsg = torch.empty_like(ref)
+    K.conv_gemm(x0=xd, w=wd, bias=bd, out0=ref, save0=rth, save1=rsg, B=B, T_in=T, T_out=T, M=2 * Rr, C0=Rr,
+                taps=taps, epilogue=K.EPI_GATE, cond=cd, cond_T=Tz)
+    xp = torch.empty(2 * B * Rr * T, dtype=torch.float16, device=DEV)
+    wp = torch.empty(2 * ks * Rr * 2 * Rr, dtype=torch.float16, device=DEV)
+    out = torch.empty_like(ref); th = torch.empty_like(ref); sg = torch.empty_like(ref)
+    K.f16x3_split_activations(xd, xp, B, Rr, T)
+    K.f16x3_pack_gate_weights(wd, wp, ks, Rr, 2 * Rr, 256.0)
+    K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save0=th, save1=sg, bias=bd, cond=cd, cond_T=Tz, B=B, T=T, R=Rr, ks=ks,
+                      dilation=d, w_scale_inv=1.0 / 256.0)
+    assert torch.isfinite(out).all()
+    for got, want, nm in ((out, ref, 'gated'), (th, rth, 'tanh'), (sg, rsg, 'sigmoid')):
+        err = float((got - want).abs().max())
+        assert err <= 2e-5, '%s differs from the fp32 engine by %.3e' % (nm, err)
+    assert float((th * sg - out).abs().max()) <= 1e-6
+    # sampled points against fp64
+    g2 = torch.Generator().manual_seed(7)
+    n = 600
+    bb = torch.randint(0, B, (n,), generator=g2); cc = torch.randint(0, Rr, (n,), generator=g2)
+    tt = torch.randint(0, T, (n,), generator=g2)
+    tt[:150] = torch.randint(0, min(T, (ks - 1) * d + 2), (150,), generator=g2)
+    x64, w64, got = x.double(), w.double(), out.cpu()
+    worst = worst_ref = 0.0
+    refc = ref.cpu()
+    for i in range(n):
+        bi, ci, ti = int(bb[i]), int(cc[i]), int(tt[i])
+        pre = torch.zeros(2, dtype=torch.float64)
+        for j, sh in enumerate(taps):
+            if ti + sh >= 0:
+                xv = x64[bi, :, ti + sh]
+                pre[0] += (xv * w64[j, :, ci]).sum()
+                pre[1] += (xv * w64[j, :, Rr + ci]).sum()
+        pre[0] += float(b[ci]) + float(cond[bi, ci, ti // ratio])
+        pre[1] += float(b[Rr + ci]) + float(cond[bi, Rr + ci, ti // ratio])
+        want = float(torch.tanh(pre[0]) * torch.sigmoid(pre[1]))
+        worst = max(worst, abs(float(got[bi, ci, ti]) - want))
+        worst_ref = max(worst_ref, abs(float(refc[bi, ci, ti]) - want))
+    assert worst < 2e-5, 'f16x3 gate outputs differ from fp64 by %.3e (fp32 engine: %.3e)' % (worst, worst_ref)
+
+
 def test_accum_split_and_two_sources(K):
     B, T, Cg, S, Rr = 2, 512, 32, 64, 32
     gated, w, b = rnd(B, T, Cg, seed=1), rnd(Cg, S + Rr, seed=2, s=0.2), rnd(S + Rr, seed=3)

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build' + os.environ.get('VQW_BUILD_SUFFIX', ''))
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, os.environ.get('VQW_LIB_NAME', 'libvqwave.so'))
-SOURCES = ['common', 'conv_gemm', 'wgrad_gemm', 'pointwise', 'vq', 'wrappers', 'ar_decode', 'ar_persist']
+SOURCES = ['common', 'conv_gemm', 'wgrad_gemm', 'pointwise', 'vq', 'wrappers', 'ar_decode', 'ar_persist', 'gate_f16x3']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('VQW_EXTRA_FLAGS', '').split()
 

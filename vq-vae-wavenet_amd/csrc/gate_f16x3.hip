@@ -1,0 +1,253 @@
+// EXPERIMENTAL (opt-in, VQW_GATE_F16X3=1 in model.py): the decoder's gate conv (wavenet_ops.py:104-114) as an
+// fp32-accurate contraction on the fp16 matrix pipe of gfx950.  DESIGN.md 3.2b has the arithmetic and its
+// measured error: every fp32 operand is split exactly enough into two fp16 pieces, x = h1 + h2,
+// h2 = fp16(x - h1), and  a*b ~ a1 b1 + a1 b2 + a2 b1  (every term exact in the fp32 accumulator of
+// v_mfma_f32_32x32x16_f16; the dropped a2 b2 is 2^-22 per product).  Same bytes per operand element as fp32,
+// three MFMAs of the 16x faster pipe instead of eight fp32 ones per 32x32x16 block.
+//
+// Operand planes ("chunk-major"): P[plane 0..1][channel chunk of 8][row][8 fp16]; a row is an output channel
+// (weights) or a (batch, time) position (activations).  The 16-byte entries of 32 consecutive rows are contiguous:
+// one 64-lane x 16-byte load fetches a 32-row x 16-k MFMA operand fragment in the lane order of the MFMA, and the
+// dilation shift of a tap is a row offset (rows before the start of a batch row read as zero through the buffer
+// range check: the causal left padding of conv1d_v2, wavenet_ops.py:81).
+//
+// Block = 256 output channels (128 filter + the 128 matching gate channels, so tanh * sigmoid meets in one lane)
+// x 256 time steps; four waves, each all 256 channels x 64 time steps (16 accumulator tiles in AGPRs); K step = 16
+// input channels of one tap; operands through VGPRs into a 4-stage LDS ring (requested three steps ahead, written
+// one step ahead, one barrier per step).
+#include "vqw_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ u16 f16_bits(_Float16 h) { return __builtin_bit_cast(u16, h); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& p0, uint4& p1) {
+    u16 a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h1 = (_Float16)x[e];            // round to nearest even
+        a[e] = f16_bits(h1);
+        b[e] = f16_bits((_Float16)(x[e] - (float)h1)); // the difference is exact in fp32
+    }
+    p0 = make_uint4(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16), a[4] | ((unsigned)a[5] << 16), a[6] | ((unsigned)a[7] << 16));
+    p1 = make_uint4(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16), b[4] | ((unsigned)b[5] << 16), b[6] | ((unsigned)b[7] << 16));
+}
+
+// x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16
+__global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T) {
+    const size_t NB = (size_t)B * T;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NB * (C / 8)) return;
+    const size_t row = i % NB;
+    const int kc = (int)(i / NB);
+    const int b = (int)(row / T), t = (int)(row % T);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = x[((size_t)b * C + kc * 8 + e) * T + t];
+    uint4 p0, p1;
+    split8(v, p0, p1);
+    planes[(size_t)kc * NB + row] = p0;
+    planes[((size_t)(C / 8) + kc) * NB + row] = p1;
+}
+
+// w [ks][R][ldw] (kernel[k, Cin, Cout], filter columns 0..R-1, gate columns R..2R-1) -> planes [2][ks*R/8][2R][8],
+// rows in block order: row m' = 256 mt + i is filter channel 128 mt + i (i < 128) or gate channel 128 mt + i - 128
+__global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int ks, int R, int ldw, float scale) {
+    const int M = 2 * R, KC = ks * R / 8;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KC * M) return;
+    const int mp = i % M, kc = i / M;
+    const int mt = mp / 256, ii = mp % 256;
+    const int col = ii < 128 ? 128 * mt + ii : R + 128 * mt + (ii - 128);
+    const int j = kc / (R / 8), c0 = (kc % (R / 8)) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[((size_t)j * R + c0 + e) * ldw + col] * scale;
+    uint4 p0, p1;
+    split8(v, p0, p1);
+    planes[(size_t)kc * M + mp] = p0;
+    planes[((size_t)KC + kc) * M + mp] = p1;
+}
+
+struct GateArgs {
+    vqw_f16x3_gate_desc d;
+    int NB;        // B * T rows of the activation planes
+    int ratio;     // T / cond_T
+};
+
+constexpr int NSTG = 4, STG_BYTES = 32 * 1024, PIECES = 8;   // per wave and stage: 4 weight + 4 activation pieces of 1 KiB
+
+__global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const vqw_f16x3_gate_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int R = d.R, M = 2 * R, T = d.T;
+    const int n_mt = R / 128;
+    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;     // 256 | T: a block never straddles two batch rows
+    const int b = n0 / T, t0 = n0 - b * T;
+    const int KCA = d.ks * R / 8, KCB = R / 8, spt = R / 16;  // K steps per tap
+    const int nsteps = d.ks * spt;
+    const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(d.wp, (unsigned)((size_t)2 * KCA * M * 16));
+    const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(d.xp, (unsigned)((size_t)2 * KCB * a.NB * 16));
+
+    // Stage image: 16 weight pieces (tile i, plane p at (i * 2 + p) KiB) then 16 activation pieces.  Wave wv moves
+    // pieces wv*4 .. wv*4+3 of either kind; lane = (k half, row) as the MFMA wants it.
+    int voffA[4], voffB[4], trow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wv * 4 + i, tile = q >> 1, p = q & 1;
+        voffA[i] = ((p * KCA + lhi) * M + mt * 256 + tile * 32 + l31) * 16;
+        voffB[i] = ((p * KCB + lhi) * a.NB + n0 + tile * 32 + l31) * 16;
+        trow[i] = t0 + tile * 32 + l31;                      // time of this lane's activation row
+    }
+    f32x4 rg[PIECES];
+    auto rissue = [&](int s) {
+        const int j = s / spt, kc = (s - j * spt) * 2;
+        const int shift = (d.ks - 1 - j) * d.dilation;       // tap j reads x[t - (ks-1-j) d]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * M * 16, 0);
+            const int vb = (trow[i] >= shift) ? voffB[i] + (kc * a.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
+            rg[4 + i] = vqw_buf_load4(rb, vb, 0);
+        }
+    };
+    auto rcommit = [&](int s) {
+        char* dst = smem + (s % NSTG) * STG_BYTES + wv * 4 * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(dst + i * 1024) = rg[i];
+            *reinterpret_cast<f32x4*>(dst + 16 * 1024 + i * 1024) = rg[4 + i];
+        }
+    };
+
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    rissue(0); rcommit(0);
+    if (nsteps > 1) { rissue(1); rcommit(1); }
+    if (nsteps > 2) rissue(2);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stages <= s + 1 are in LDS, stage s - 2's buffer is free
+        if (s + 2 < nsteps) rcommit(s + 2);
+        if (s + 3 < nsteps) rissue(s + 3);
+        const char* st = smem + (s % NSTG) * STG_BYTES + lane * 16;
+        uint4 af[8][2], bf[2][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + p) * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {   // small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[j][1]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][1]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: + bias + upsampled condition (add_condition, wavenet_ops.py:93-101), tanh(filter) * sigmoid(gate)
+    const float* cb = d.cond ? d.cond + (size_t)b * d.cond_bstride : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            float addf[4][2], addg[4][2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 128 * mt + 32 * i + 8 * v4 + 4 * lhi + e;
+                const float bfv = d.bias ? d.bias[c] : 0.0f, bgv = d.bias ? d.bias[R + c] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int tz = (t0 + 64 * wv + 32 * j) / a.ratio;    // 32 | ratio: one frame per tile row
+                    addf[e][j] = bfv + (cb ? cb[(size_t)c * d.cond_T + tz] : 0.0f);
+                    addg[e][j] = bgv + (cb ? cb[(size_t)(R + c) * d.cond_T + tz] : 0.0f);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 128 * mt + 32 * i + 8 * v4 + 4 * lhi + e;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int t = t0 + 64 * wv + 32 * j + l31;
+                    const float th = tanh_f(acc[i][j][v4 * 4 + e] * d.w_scale_inv + addf[e][j]);
+                    const float sg = sigmoid_f(acc[i + 4][j][v4 * 4 + e] * d.w_scale_inv + addg[e][j]);
+                    const size_t o = ((size_t)b * R + c) * T + t;
+                    d.out0[o] = th * sg;
+                    if (d.save0) d.save0[o] = th;
+                    if (d.save1) d.save1[o] = sg;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(x && planes, "vqw_f16x3_split_activations: null pointer");
+    VQW_CHECK(B > 0 && T > 0 && C > 0 && C % 8 == 0, "vqw_f16x3_split_activations: C must be a positive multiple of 8 (got %d)", C);
+    const size_t n = (size_t)B * T * (C / 8);
+    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T);
+    VQW_LAUNCH_CHECK("vqw_f16x3_split_activations");
+    return 0;
+}
+
+int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(w && planes, "vqw_f16x3_pack_gate_weights: null pointer");
+    VQW_CHECK(ks >= 1 && R > 0 && R % 128 == 0 && ldw >= 2 * R, "vqw_f16x3_pack_gate_weights: needs R %% 128 == 0, ldw >= 2R (R=%d ldw=%d)", R, ldw);
+    const int n = (ks * R / 8) * 2 * R;
+    hipLaunchKernelGGL(pack_gate_w_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale);
+    VQW_LAUNCH_CHECK("vqw_f16x3_pack_gate_weights");
+    return 0;
+}
+
+int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(dp, "vqw_f16x3_gate_conv: null descriptor");
+    const vqw_f16x3_gate_desc& d = *dp;
+    VQW_CHECK(d.xp && d.wp && d.out0, "vqw_f16x3_gate_conv: null operand");
+    VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_gate_conv: T must be a positive multiple of 256 (got %d)", d.T);
+    VQW_CHECK(d.R > 0 && d.R % 128 == 0, "vqw_f16x3_gate_conv: R must be a multiple of 128 (got %d)", d.R);
+    VQW_CHECK(d.ks >= 1 && d.ks <= 8 && d.dilation >= 1, "vqw_f16x3_gate_conv: bad kernel size %d / dilation %d", d.ks, d.dilation);
+    VQW_CHECK((size_t)2 * (d.R / 8) * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_gate_conv: activation planes exceed 2 GiB");
+    VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_gate_conv: w_scale_inv must be positive");
+    GateArgs a;
+    a.d = d;
+    a.NB = d.B * d.T;
+    a.ratio = 1;
+    if (d.cond) {
+        VQW_CHECK(d.cond_T > 0 && d.T % d.cond_T == 0 && (d.T / d.cond_T) % 32 == 0,
+                  "vqw_f16x3_gate_conv: T / cond_T must be a multiple of 32 (T=%d cond_T=%d)", d.T, d.cond_T);
+        a.ratio = d.T / d.cond_T;
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gate_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+        return vqw_set_error("vqw_f16x3_gate_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
+    const int blocks = (d.R / 128) * (a.NB / 256);
+    hipLaunchKernelGGL(gate_f16x3_kernel, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    VQW_LAUNCH_CHECK("vqw_f16x3_gate_conv");
+    return 0;
+}
+
+}  // extern "C"

@@ -194,6 +194,53 @@ def relu_bn_fwd(x, r, scale, shift):
     L.check(L.lib().vqw_relu_bn_fwd(L.ptr(x), L.ptr(r), L.ptr(scale), L.ptr(shift), B, Cc, T, L.stream()))
 
 
+# ---- experimental: gate conv on the fp16 matrix pipe with two-plane operands (include/vqwave.h)
+def _need_planes(t, n_halves, what):
+    if t is None or t.dtype != torch.float16 or t.numel() < n_halves:
+        raise ValueError('%s must be a float16 tensor with at least %d elements' % (what, n_halves))
+    L.require_cuda(t)
+
+
+def f16x3_split_activations(x, planes, B, Cc, T):
+    """x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16."""
+    _need(x, B * Cc * T, 'x')
+    _need_planes(planes, 2 * B * Cc * T, 'planes')
+    L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, L.stream()))
+
+
+def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale):
+    _need(w, (ks * R - 1) * ldw + 2 * R, 'w')
+    _need_planes(planes, 2 * ks * R * 2 * R, 'planes')
+    L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), L.stream()))
+
+
+def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,
+                    cond_bstride=0, save0=None, save1=None):
+    _need_planes(xp, 2 * B * R * T, 'xp')
+    _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
+    _need(out0, B * R * T, 'out0')
+    for t, nm in ((save0, 'save0'), (save1, 'save1')):
+        if t is not None:
+            _need(t, B * R * T, nm)
+    if bias is not None:
+        _need(bias, 2 * R, 'bias')
+    if cond is not None:
+        bs = cond_bstride if cond_bstride else 2 * R * cond_T
+        _need(cond, (B - 1) * bs + 2 * R * cond_T, 'cond')
+        cond_bstride = bs
+    d = L.F16x3GateDesc()
+    d.xp, d.wp = xp.data_ptr(), wp.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.cond = None if cond is None else cond.data_ptr()
+    d.out0 = out0.data_ptr()
+    d.save0 = None if save0 is None else save0.data_ptr()
+    d.save1 = None if save1 is None else save1.data_ptr()
+    d.cond_bstride = cond_bstride
+    d.B, d.T, d.R, d.ks, d.dilation, d.cond_T = B, T, R, ks, dilation, cond_T
+    d.w_scale_inv = float(w_scale_inv)
+    L.check(L.lib().vqw_f16x3_gate_conv(C.byref(d), L.stream()))
+
+
 def mfcc(x, mel, out, *, n_keep=13):
     """x [B][T], mel [201][n_mel] -> out [B][C_out][ceil(T/160)] (channels >= n_keep zeroed)."""
     B, T = x.shape
