@@ -302,8 +302,9 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
 int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, vqw_stream_t s);
 /* w [ks][R][ldw] fp32 (kernel[k, Cin, Cout]: filter columns 0..R-1, gate columns R..2R-1), multiplied by `scale`
  * (a power of two that lifts the residual plane into fp16's normal range, e.g. 256) -> planes [2][ks*R/8][2R][8]
- * with the output channels in the kernel's block order; R % 128 == 0 */
-int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, vqw_stream_t s);
+ * with the output channels in the kernel's block order; R % 128 == 0.  `count` layers stored back to back (w: ks*R*ldw
+ * floats apart, planes: 2*ks*R*2R halves apart) are packed by one launch */
+int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count, vqw_stream_t s);
 
 typedef struct vqw_f16x3_gate_desc {
     const void* xp;      /* activation planes of the layer input [B][R][T]                  */
@@ -313,12 +314,33 @@ typedef struct vqw_f16x3_gate_desc {
     float* out0;         /* tanh(filter) * sigmoid(gate)  [B][R][T]                         */
     float* save0;        /* tanh    [B][R][T] or NULL (kept for the backward pass)          */
     float* save1;        /* sigmoid [B][R][T] or NULL                                       */
+    void* out_planes;    /* out0 once more as fp16 planes [2][R/8][B*T][8] (input of vqw_f16x3_out_conv) or NULL */
     int64_t cond_bstride;
     int32_t B, T, R, ks, dilation, cond_T;
     float w_scale_inv;   /* 1 / scale of the weight planes                                  */
 } vqw_f16x3_gate_desc;
 /* T % 256 == 0, R % 128 == 0, (T / cond_T) % 32 == 0; tap j reads x[t - (ks-1-j)*dilation], zero before t = 0 */
 int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
+
+/* w [K][ldw] fp32 (row k, column m), times `scale` -> planes [2][K/8][M][8]; K % 8 == 0; `count` matrices back to back
+ * (w: K*ldw floats apart, planes: 2*K*M halves apart) */
+int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count, vqw_stream_t s);
+
+/* The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
+ * skip[b][m][t] += (W g)[m] + bias[m] for m < S;  net_out[b][c][t] = net_in[b][c][t] + (W g)[S+c] + bias[S+c],
+ * and net_out once more as planes for the next layer's gate conv.  T % 256 == 0, R % 256 == 0, S % 256 == 0.       */
+typedef struct vqw_f16x3_out_desc {
+    const void* xp;        /* gated planes [2][R/8][B*T][8]                                  */
+    const void* wp;        /* vqw_f16x3_pack_weights(out_w [R][S+R], K = R, M = S+R)         */
+    const float* bias;     /* [S+R] or NULL                                                  */
+    float* skip;           /* [B][S][T], accumulated in place                                */
+    const float* net_in;   /* [B][R][T]                                                      */
+    float* net_out;        /* [B][R][T]                                                      */
+    void* net_out_planes;  /* [2][R/8][B*T][8] or NULL                                       */
+    int32_t B, T, R, S;
+    float w_scale_inv;
+} vqw_f16x3_out_desc;
+int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -362,6 +362,45 @@ def test_gate_conv_f16x3_matches_fp32_engine(K, B, T, Rr, ks, d):
     assert worst < 2e-5, 'f16x3 gate outputs differ from fp64 by %.3e (fp32 engine: %.3e)' % (worst, worst_ref)
 
 
+@pytest.mark.parametrize('B,T', [(2, 512), (8, 6656)])
+def test_out_conv_f16x3_matches_fp32_engine(K, B, T):
+    """Experimental 1x1 skip + residual conv on the fp16 matrix pipe, fed by the gate kernel's plane output and
+    writing the next layer's input planes: against the fp32 engine's ACCUM_SPLIT launch on the same inputs (2e-5 of
+    the tensor max) and the planes against a split of the fp32 result (bit-identical fp16 pieces)."""
+    Rr, S, ks, d = 256, 512, 3, 2
+    gen = torch.Generator().manual_seed(77 + T)
+    x = torch.randn(B, Rr, T, generator=gen)
+    wg = torch.randn(ks, Rr, 2 * Rr, generator=gen) * 0.05
+    wo = torch.randn(Rr, S + Rr, generator=gen) * 0.08
+    bo = torch.randn(S + Rr, generator=gen) * 0.3
+    skip0 = torch.randn(B, S, T, generator=gen)
+    xd, wgd, wod, bod = x.to(DEV), wg.to(DEV), wo.to(DEV), bo.to(DEV)
+    xp = torch.empty(2 * B * Rr * T, dtype=torch.float16, device=DEV)
+    gp = torch.empty_like(xp); np_ = torch.empty_like(xp); np_ref = torch.empty_like(xp)
+    wgp = torch.empty(2 * ks * Rr * 2 * Rr, dtype=torch.float16, device=DEV)
+    wop = torch.empty(2 * Rr * (S + Rr), dtype=torch.float16, device=DEV)
+    gated = torch.empty(B, Rr, T, device=DEV)
+    K.f16x3_split_activations(xd, xp, B, Rr, T)
+    K.f16x3_pack_gate_weights(wgd, wgp, ks, Rr, 2 * Rr, 256.0)
+    K.f16x3_gate_conv(xp=xp, wp=wgp, out0=gated, out_planes=gp, B=B, T=T, R=Rr, ks=ks, dilation=d, w_scale_inv=1.0 / 256.0)
+    gp_ref = torch.empty_like(xp)
+    K.f16x3_split_activations(gated, gp_ref, B, Rr, T)
+    assert torch.equal(gp.view(torch.int16), gp_ref.view(torch.int16)), 'gated planes differ from a split of the gated tensor'
+    # fp32 engine reference
+    skip_ref = skip0.to(DEV); net_ref = torch.empty(B, Rr, T, device=DEV)
+    K.conv_gemm(x0=gated, w=wod, bias=bod, out0=skip_ref, out1=net_ref, aux1=xd, B=B, T_in=T, T_out=T, M=S + Rr, M0=S,
+                C0=Rr, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
+    skip = skip0.to(DEV); net = torch.empty(B, Rr, T, device=DEV)
+    K.f16x3_pack_weights(wod, wop, Rr, S + Rr, S + Rr, 64.0)
+    K.f16x3_out_conv(xp=gp, wp=wop, bias=bod, skip=skip, net_in=xd, net_out=net, net_out_planes=np_, B=B, T=T, R=Rr, S=S,
+                     w_scale_inv=1.0 / 64.0)
+    for got, want, nm in ((skip, skip_ref, 'skip'), (net, net_ref, 'net')):
+        err = float((got - want).abs().max()) / float(want.abs().max())
+        assert err <= 2e-5, '%s differs from the fp32 engine by %.3e of max' % (nm, err)
+    K.f16x3_split_activations(net, np_ref, B, Rr, T)
+    assert torch.equal(np_.view(torch.int16), np_ref.view(torch.int16)), 'net planes differ from a split of net_out'
+
+
 def test_accum_split_and_two_sources(K):
     B, T, Cg, S, Rr = 2, 512, 32, 64, 32
     gated, w, b = rnd(B, T, Cg, seed=1), rnd(Cg, S + Rr, seed=2, s=0.2), rnd(S + Rr, seed=3)

@@ -52,8 +52,35 @@ def timeit(f, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-split(); pack()
+S = 512
+wo = (torch.randn(R, S + R, generator=g) * 0.08).to(dev)
+bo = (torch.randn(S + R, generator=g) * 0.3).to(dev)
+skip = torch.zeros(B, S, T, device=dev); net2 = torch.empty(B, R, T, device=dev)
+gp = torch.empty_like(xp); np_ = torch.empty_like(xp)
+wop = torch.empty(2 * R * (S + R), dtype=torch.float16, device=dev)
+
+
+def gate_planes():
+    K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save0=th, save1=sg, bias=b, cond=cond, cond_T=Tz, B=B, T=T, R=R, ks=ks,
+                      dilation=d, w_scale_inv=1.0 / 256.0, out_planes=gp)
+
+
+def out_fp32():
+    K.conv_gemm(x0=out, w=wo, bias=bo, out0=skip, out1=net2, aux1=x, B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
+                epilogue=K.EPI_ACCUM_SPLIT, tile=12)
+
+
+def out_x3():
+    K.f16x3_out_conv(xp=gp, wp=wop, bias=bo, skip=skip, net_in=x, net_out=net2, net_out_planes=np_, B=B, T=T, R=R, S=S,
+                     w_scale_inv=1.0 / 256.0)
+
+
+split(); pack(); gate_planes()
+K.f16x3_pack_weights(wo, wop, R, S + R, S + R, 256.0)
 flop = 2.0 * B * T * 2 * R * ks * R
-for name, f in (('fp32-MFMA gate conv', fp32), ('f16x3 gate conv', gate), ('activation split pass', split), ('weight pack', pack)):
+flop_out = 2.0 * B * T * R * (S + R)
+for name, f in (('fp32-MFMA gate conv', fp32), ('f16x3 gate conv', gate), ('f16x3 gate conv + planes', gate_planes),
+                ('activation split pass', split), ('weight pack', pack), ('fp32-MFMA out conv', out_fp32), ('f16x3 out conv', out_x3)):
     us = timeit(f)
-    print('%-24s %8.1f us%s' % (name, us, '  %.1f TFLOP/s fp32-equivalent' % (flop / us * 1e-6) if 'gate' in name else ''))
+    fl = flop if 'gate' in name else (flop_out if 'out' in name else 0)
+    print('%-26s %8.1f us%s' % (name, us, '  %.1f TFLOP/s fp32-equivalent' % (fl / us * 1e-6) if fl else ''))

@@ -56,11 +56,18 @@ class ArWeights(C.Structure):
 class F16x3GateDesc(C.Structure):
     _fields_ = [
         ('xp', _fp), ('wp', _fp), ('bias', _fp), ('cond', _fp), ('out0', _fp), ('save0', _fp), ('save1', _fp),
-        ('cond_bstride', C.c_int64),
+        ('out_planes', _fp), ('cond_bstride', C.c_int64),
         ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('ks', C.c_int32), ('dilation', C.c_int32),
         ('cond_T', C.c_int32), ('w_scale_inv', C.c_float),
     ]
 
+
+class F16x3OutDesc(C.Structure):
+    _fields_ = [
+        ('xp', _fp), ('wp', _fp), ('bias', _fp), ('skip', _fp), ('net_in', _fp), ('net_out', _fp),
+        ('net_out_planes', _fp),
+        ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('S', C.c_int32), ('w_scale_inv', C.c_float),
+    ]
 
 _i, _f, _sz, _i64 = C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
@@ -101,8 +108,10 @@ SIGNATURES = {
     'vqw_ar_decode_wait': (_i, [_fp]),
     'vqw_ar_decode_destroy': (_i, [_fp]),
     'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _fp]),
-    'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _fp]),
+    'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),
+    'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),
+    'vqw_f16x3_out_conv': (_i, [C.POINTER(F16x3OutDesc), _fp]),
 }
 
 _lib = None

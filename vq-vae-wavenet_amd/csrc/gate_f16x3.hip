@@ -62,6 +62,8 @@ __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict_
 // rows in block order: row m' = 256 mt + i is filter channel 128 mt + i (i < 128) or gate channel 128 mt + i - 128
 __global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int ks, int R, int ldw, float scale) {
     const int M = 2 * R, KC = ks * R / 8;
+    w += (size_t)blockIdx.y * ks * R * ldw;          // one layer per grid row
+    planes += (size_t)blockIdx.y * 2 * KC * M;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= KC * M) return;
     const int mp = i % M, kc = i / M;
@@ -77,46 +79,69 @@ __global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restric
     planes[((size_t)KC + kc) * M + mp] = p1;
 }
 
+// w [K][ldw] fp32 (columns = output rows m) -> planes [2][K/8][M][8], natural row order
+__global__ void pack_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int K, int M, int ldw, float scale) {
+    const int KC = K / 8;
+    w += (size_t)blockIdx.y * K * ldw;
+    planes += (size_t)blockIdx.y * 2 * KC * M;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KC * M) return;
+    const int m = i % M, kc = i / M;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[(size_t)(kc * 8 + e) * ldw + m] * scale;
+    uint4 p0, p1;
+    split8(v, p0, p1);
+    planes[(size_t)kc * M + m] = p0;
+    planes[((size_t)KC + kc) * M + m] = p1;
+}
+
 struct GateArgs {
     vqw_f16x3_gate_desc d;
     int NB;        // B * T rows of the activation planes
     int ratio;     // T / cond_T
 };
+struct OutArgs {
+    vqw_f16x3_out_desc d;
+    int NB;
+};
 
 constexpr int NSTG = 4, STG_BYTES = 32 * 1024, PIECES = 8;   // per wave and stage: 4 weight + 4 activation pieces of 1 KiB
 
-__global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const vqw_f16x3_gate_desc& d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const int R = d.R, M = 2 * R, T = d.T;
-    const int n_mt = R / 128;
-    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;     // 256 | T: a block never straddles two batch rows
-    const int b = n0 / T, t0 = n0 - b * T;
-    const int KCA = d.ks * R / 8, KCB = R / 8, spt = R / 16;  // K steps per tap
-    const int nsteps = d.ks * spt;
-    const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(d.wp, (unsigned)((size_t)2 * KCA * M * 16));
-    const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(d.xp, (unsigned)((size_t)2 * KCB * a.NB * 16));
+// Geometry of one block's contraction: 256 weight rows from row m_row0 of planes with M rows, K = ks taps x Cin
+// input channels, 256 activation rows from row n0 (time t0 of its batch row) of planes with NB rows.
+struct LoopGeom {
+    const void* wp;
+    const void* xp;
+    int M, Cin, ks, dilation, NB, m_row0, n0, t0;
+};
 
+// acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: 16 accumulator tiles per wave, operands through
+// VGPRs into the 4-stage LDS ring (requested three K steps ahead, written one step ahead, one barrier per step).
+__device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, const LoopGeom& g, int wv, int lane) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int KCA = g.ks * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
+    const int nsteps = g.ks * spt;
+    const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(g.wp, (unsigned)((size_t)2 * KCA * g.M * 16));
+    const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(g.xp, (unsigned)((size_t)2 * KCB * g.NB * 16));
     // Stage image: 16 weight pieces (tile i, plane p at (i * 2 + p) KiB) then 16 activation pieces.  Wave wv moves
     // pieces wv*4 .. wv*4+3 of either kind; lane = (k half, row) as the MFMA wants it.
     int voffA[4], voffB[4], trow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = wv * 4 + i, tile = q >> 1, p = q & 1;
-        voffA[i] = ((p * KCA + lhi) * M + mt * 256 + tile * 32 + l31) * 16;
-        voffB[i] = ((p * KCB + lhi) * a.NB + n0 + tile * 32 + l31) * 16;
-        trow[i] = t0 + tile * 32 + l31;                      // time of this lane's activation row
+        voffA[i] = ((p * KCA + lhi) * g.M + g.m_row0 + tile * 32 + l31) * 16;
+        voffB[i] = ((p * KCB + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
+        trow[i] = g.t0 + tile * 32 + l31;                    // time of this lane's activation row
     }
     f32x4 rg[PIECES];
     auto rissue = [&](int s) {
         const int j = s / spt, kc = (s - j * spt) * 2;
-        const int shift = (d.ks - 1 - j) * d.dilation;       // tap j reads x[t - (ks-1-j) d]
+        const int shift = (g.ks - 1 - j) * g.dilation;       // tap j reads x[t - (ks-1-j) d]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * M * 16, 0);
-            const int vb = (trow[i] >= shift) ? voffB[i] + (kc * a.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
+            rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * g.M * 16, 0);
+            const int vb = (trow[i] >= shift) ? voffB[i] + (kc * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
             rg[4 + i] = vqw_buf_load4(rb, vb, 0);
         }
     };
@@ -128,8 +153,6 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
             *reinterpret_cast<f32x4*>(dst + 16 * 1024 + i * 1024) = rg[4 + i];
         }
     };
-
-    f32x16 acc[8][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -163,6 +186,39 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
             }
     }
+}
+
+// Four consecutive channels (rows 4 lhi .. 4 lhi + 3 of chunk kc) of one (batch, time) row as the lane's 8-byte
+// half of the 16-byte plane entries: the 64 lanes of a wave cover 32 rows x 16 bytes = 512 contiguous bytes per plane.
+__device__ __forceinline__ void store_plane_quad(void* planes, int KC, int NB, int kc, int row, int lhi, const float (&x)[4]) {
+    u16 h1[4], h2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 a = (_Float16)x[e];
+        h1[e] = f16_bits(a);
+        h2[e] = f16_bits((_Float16)(x[e] - (float)a));
+    }
+    char* base = reinterpret_cast<char*>(planes) + ((size_t)kc * NB + row) * 16 + lhi * 8;
+    *reinterpret_cast<uint2*>(base) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
+    *reinterpret_cast<uint2*>(base + (size_t)KC * NB * 16) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+}
+
+__global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const vqw_f16x3_gate_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int R = d.R, T = d.T;
+    const int n_mt = R / 128;
+    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;     // 256 | T: a block never straddles two batch rows
+    const int b = n0 / T, t0 = n0 - b * T;
+    f32x16 acc[8][2];
+    {
+        LoopGeom g;
+        g.wp = d.wp; g.xp = d.xp; g.M = 2 * R; g.Cin = R; g.ks = d.ks; g.dilation = d.dilation; g.NB = a.NB;
+        g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
+        f16x3_mainloop(acc, smem, g, wv, lane);
+    }
 
     // ---- epilogue: + bias + upsampled condition (add_condition, wavenet_ops.py:93-101), tanh(filter) * sigmoid(gate)
     const float* cb = d.cond ? d.cond + (size_t)b * d.cond_bstride : nullptr;
@@ -182,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
                     addg[e][j] = bgv + (cb ? cb[(size_t)(R + c) * d.cond_T + tz] : 0.0f);
                 }
             }
+            float gq[2][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 128 * mt + 32 * i + 8 * v4 + 4 * lhi + e;
@@ -191,10 +248,67 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
                     const float th = tanh_f(acc[i][j][v4 * 4 + e] * d.w_scale_inv + addf[e][j]);
                     const float sg = sigmoid_f(acc[i + 4][j][v4 * 4 + e] * d.w_scale_inv + addg[e][j]);
                     const size_t o = ((size_t)b * R + c) * T + t;
-                    d.out0[o] = th * sg;
+                    gq[j][e] = th * sg;
+                    d.out0[o] = gq[j][e];
                     if (d.save0) d.save0[o] = th;
                     if (d.save1) d.save1[o] = sg;
                 }
+            }
+            if (d.out_planes) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    store_plane_quad(d.out_planes, R / 8, a.NB, 16 * mt + 4 * i + v4, n0 + 64 * wv + 32 * j + l31, lhi, gq[j]);
+            }
+        }
+}
+
+// The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
+// rows 0..S-1: skip += W_s g + b_s; rows S..S+R-1: net' = net + W_r g + b_r (and net' as planes for the next gate conv).
+__global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const vqw_f16x3_out_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int R = d.R, S = d.S, T = d.T, M = S + R;
+    const int n_mt = M / 256;
+    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
+    const int b = n0 / T, t0 = n0 - b * T;
+    f32x16 acc[8][2];
+    {
+        LoopGeom g;
+        g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = R; g.ks = 1; g.dilation = 1; g.NB = a.NB;
+        g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
+        f16x3_mainloop(acc, smem, g, wv, lane);
+    }
+    const bool is_skip = mt * 256 < S;    // 256 | S: a block is all skip rows or all residual rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            const int m0 = mt * 256 + 32 * i + 8 * v4 + 4 * lhi;     // first of this lane's four rows
+            float bq[4], old[2][4], nq[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bq[e] = d.bias ? d.bias[m0 + e] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int t = t0 + 64 * wv + 32 * j + l31;
+                    old[j][e] = is_skip ? d.skip[((size_t)b * S + m0 + e) * T + t] : d.net_in[((size_t)b * R + (m0 - S) + e) * T + t];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int t = t0 + 64 * wv + 32 * j + l31;
+                    nq[j][e] = old[j][e] + (acc[i][j][v4 * 4 + e] * d.w_scale_inv + bq[e]);
+                    if (is_skip) d.skip[((size_t)b * S + m0 + e) * T + t] = nq[j][e];
+                    else d.net_out[((size_t)b * R + (m0 - S) + e) * T + t] = nq[j][e];
+                }
+            if (!is_skip && d.net_out_planes) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    store_plane_quad(d.net_out_planes, R / 8, a.NB, (m0 - S) / 8, n0 + 64 * wv + 32 * j + l31, lhi, nq[j]);
             }
         }
 }
@@ -213,13 +327,43 @@ int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int 
     return 0;
 }
 
-int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, vqw_stream_t s_) {
+int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(w && planes, "vqw_f16x3_pack_gate_weights: null pointer");
-    VQW_CHECK(ks >= 1 && R > 0 && R % 128 == 0 && ldw >= 2 * R, "vqw_f16x3_pack_gate_weights: needs R %% 128 == 0, ldw >= 2R (R=%d ldw=%d)", R, ldw);
+    VQW_CHECK(ks >= 1 && R > 0 && R % 128 == 0 && ldw >= 2 * R && count >= 1 && count <= 65535, "vqw_f16x3_pack_gate_weights: needs R %% 128 == 0, ldw >= 2R, 1 <= count <= 65535 (R=%d ldw=%d count=%d)", R, ldw, count);
     const int n = (ks * R / 8) * 2 * R;
-    hipLaunchKernelGGL(pack_gate_w_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale);
+    hipLaunchKernelGGL(pack_gate_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_gate_weights");
+    return 0;
+}
+
+int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(w && planes, "vqw_f16x3_pack_weights: null pointer");
+    VQW_CHECK(K > 0 && K % 8 == 0 && M > 0 && ldw >= M && count >= 1 && count <= 65535, "vqw_f16x3_pack_weights: needs K %% 8 == 0, ldw >= M, 1 <= count <= 65535 (K=%d M=%d ldw=%d count=%d)", K, M, ldw, count);
+    const int n = (K / 8) * M;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale);
+    VQW_LAUNCH_CHECK("vqw_f16x3_pack_weights");
+    return 0;
+}
+
+int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(dp, "vqw_f16x3_out_conv: null descriptor");
+    const vqw_f16x3_out_desc& d = *dp;
+    VQW_CHECK(d.xp && d.wp && d.skip && d.net_in && d.net_out, "vqw_f16x3_out_conv: null operand");
+    VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_out_conv: T must be a positive multiple of 256 (got %d)", d.T);
+    VQW_CHECK(d.R > 0 && d.R % 256 == 0 && d.S > 0 && d.S % 256 == 0, "vqw_f16x3_out_conv: R and S must be multiples of 256 (R=%d S=%d)", d.R, d.S);
+    VQW_CHECK((size_t)2 * (d.R / 8) * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_out_conv: activation planes exceed 2 GiB");
+    VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_out_conv: w_scale_inv must be positive");
+    OutArgs a;
+    a.d = d;
+    a.NB = d.B * d.T;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(out_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+        return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
+    const int blocks = ((d.S + d.R) / 256) * (a.NB / 256);
+    hipLaunchKernelGGL(out_f16x3_kernel, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");
     return 0;
 }
 

@@ -208,14 +208,42 @@ def f16x3_split_activations(x, planes, B, Cc, T):
     L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, L.stream()))
 
 
-def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale):
-    _need(w, (ks * R - 1) * ldw + 2 * R, 'w')
-    _need_planes(planes, 2 * ks * R * 2 * R, 'planes')
-    L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), L.stream()))
+def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1):
+    """`count` layers back to back in `w` ([count][ks][R][ldw]) and in `planes`."""
+    _need(w, (count - 1) * ks * R * ldw + (ks * R - 1) * ldw + 2 * R, 'w')
+    _need_planes(planes, count * 2 * ks * R * 2 * R, 'planes')
+    L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), count, L.stream()))
+
+
+def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1):
+    """w [count][K][ldw] fp32 -> planes [count][2][K/8][M][8] fp16 of scale * w."""
+    _need(w, (count - 1) * Kd * ldw + (Kd - 1) * ldw + M, 'w')
+    _need_planes(planes, count * 2 * Kd * M, 'planes')
+    L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, L.stream()))
+
+
+def f16x3_out_conv(*, xp, wp, skip, net_in, net_out, B, T, R, S, w_scale_inv, bias=None, net_out_planes=None):
+    _need_planes(xp, 2 * B * R * T, 'xp')
+    _need_planes(wp, 2 * R * (S + R), 'wp')
+    _need(skip, B * S * T, 'skip')
+    _need(net_in, B * R * T, 'net_in')
+    _need(net_out, B * R * T, 'net_out')
+    if bias is not None:
+        _need(bias, S + R, 'bias')
+    if net_out_planes is not None:
+        _need_planes(net_out_planes, 2 * B * R * T, 'net_out_planes')
+    d = L.F16x3OutDesc()
+    d.xp, d.wp = xp.data_ptr(), wp.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.skip, d.net_in, d.net_out = skip.data_ptr(), net_in.data_ptr(), net_out.data_ptr()
+    d.net_out_planes = None if net_out_planes is None else net_out_planes.data_ptr()
+    d.B, d.T, d.R, d.S = B, T, R, S
+    d.w_scale_inv = float(w_scale_inv)
+    L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 
 
 def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,
-                    cond_bstride=0, save0=None, save1=None):
+                    cond_bstride=0, save0=None, save1=None, out_planes=None):
     _need_planes(xp, 2 * B * R * T, 'xp')
     _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
     _need(out0, B * R * T, 'out0')
@@ -235,6 +263,9 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     d.out0 = out0.data_ptr()
     d.save0 = None if save0 is None else save0.data_ptr()
     d.save1 = None if save1 is None else save1.data_ptr()
+    if out_planes is not None:
+        _need_planes(out_planes, 2 * B * R * T, 'out_planes')
+    d.out_planes = None if out_planes is None else out_planes.data_ptr()
     d.cond_bstride = cond_bstride
     d.B, d.T, d.R, d.ks, d.dilation, d.cond_T = B, T, R, ks, dilation, cond_T
     d.w_scale_inv = float(w_scale_inv)

@@ -84,7 +84,9 @@ class VQVAE:
         self.grad_sync = None   # parallel.GradAllReduce when training data-parallel
         self.overlap_wgrad = os.environ.get('VQW_OVERLAP', '1') != '0'   # decoder backward on two streams
         # experimental: the decoder's gate convs on the fp16 matrix pipe with two-plane operands
-        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '1'
+        # '1': gate convs; '2': gate convs + the 1x1 skip/residual convs (which then hand over the next layer's planes)
+        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2')
+        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '2'
         self._side = None
         self._build_layout()
         self._init_params(seed)
@@ -295,7 +297,11 @@ class VQVAE:
         ws['sg'] = [e(B, R, T) for _ in range(L)]
         if self.gate_f16x3:
             ws['xp'] = torch.empty(2 * B * R * T, dtype=torch.float16, device=dev)
-            ws['wp'] = [torch.empty(2 * self.ks * R * 2 * R, dtype=torch.float16, device=dev) for _ in range(L)]
+            ws['wp_all'] = torch.empty(L, 2 * self.ks * R * 2 * R, dtype=torch.float16, device=dev)
+            ws['wp'] = [ws['wp_all'][l] for l in range(L)]
+            ws['gp'] = torch.empty(2 * B * R * T, dtype=torch.float16, device=dev)
+            ws['wop_all'] = torch.empty(L, 2 * R * (S + R), dtype=torch.float16, device=dev)
+            ws['wop'] = [ws['wop_all'][l] for l in range(L)]
         ws['h1'] = e(B, S, T)
         ws['logits'] = e(B, Q, T)
         # backward
@@ -391,17 +397,26 @@ class VQVAE:
         # fp16x3 needs whole 256-step tiles inside a batch row, 128-channel blocks and one condition frame per 32 steps;
         # |w| < 255 and |net| < 65504 (fp16 range of the leading planes) are assumed, not checked
         f16x3 = self.gate_f16x3 and T % 256 == 0 and R % 128 == 0 and (T // Tz) % 32 == 0
+        f16x3_out = f16x3 and self.out_f16x3 and R % 256 == 0 and S % 256 == 0    # the 1x1 skip + residual conv too; it hands the next layer its planes
+        if f16x3:      # this step's weights of all layers as fp16 planes, one launch per kind
+            K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, 256.0, count=L)
+            if f16x3_out:
+                K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, 256.0, count=L)
         for l, d in enumerate(self.dil):
             if f16x3:
-                K.f16x3_split_activations(net[l], ws['xp'], B, R, T)
-                K.f16x3_pack_gate_weights(P['gated_w'][l], ws['wp'][l], self.ks, R, 2 * R, 256.0)
+                if l == 0 or not f16x3_out:
+                    K.f16x3_split_activations(net[l], ws['xp'], B, R, T)
                 K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if save else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
                                   cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T=T, R=R, ks=self.ks,
-                                  dilation=d, w_scale_inv=1.0 / 256.0)
-                K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
-                            aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
-                            epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])
+                                  dilation=d, w_scale_inv=1.0 / 256.0, out_planes=ws['gp'] if f16x3_out else None)
+                if f16x3_out:
+                    K.f16x3_out_conv(xp=ws['gp'], wp=ws['wop'][l], bias=P['out_b'][l], skip=ws['skip'], net_in=net[l],
+                                     net_out=net[l + 1], net_out_planes=ws['xp'], B=B, T=T, R=R, S=S, w_scale_inv=1.0 / 256.0)
+                else:
+                    K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
+                                aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
+                                epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])
                 continue
             K.conv_gemm(x0=net[l], w=P['gated_w'][l], bias=P['gated_b'][l], out0=ws['gated'][l],
                         save0=ws['th'][l] if save else None, save1=ws['sg'][l] if save else None,
