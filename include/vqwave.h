@@ -318,6 +318,8 @@ typedef struct vqw_f16x3_gate_desc {
     int64_t cond_bstride;
     int32_t B, T, R, ks, dilation, cond_T;
     float w_scale_inv;   /* 1 / scale of the weight planes                                  */
+    int32_t out_planes_kc0, out_planes_KC;  /* out_planes holds KC chunks of 8 channels per plane, this layer's start at
+                                             * chunk kc0 (several layers side by side); 0, 0 = exactly this layer's R/8 */
 } vqw_f16x3_gate_desc;
 /* T % 256 == 0, R % 128 == 0, (T / cond_T) % 32 == 0; tap j reads x[t - (ks-1-j)*dilation], zero before t = 0 */
 int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
@@ -328,17 +330,21 @@ int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, 
 
 /* The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
  * skip[b][m][t] += (W g)[m] + bias[m] for m < S;  net_out[b][c][t] = net_in[b][c][t] + (W g)[S+c] + bias[S+c],
- * and net_out once more as planes for the next layer's gate conv.  T % 256 == 0, R % 256 == 0, S % 256 == 0.       */
+ * and net_out once more as planes for the next layer's gate conv.  T % 256 == 0, R % 256 == 0, S % 256 == 0.
+ * With R = 0 and Cin = L*R_layer over the gated planes of all L layers side by side it is the whole skip path
+ * as ONE contraction (skip += sum_l W_s,l g_l), with S = 0 the residual half alone.                                  */
 typedef struct vqw_f16x3_out_desc {
     const void* xp;        /* gated planes [2][R/8][B*T][8]                                  */
-    const void* wp;        /* vqw_f16x3_pack_weights(out_w [R][S+R], K = R, M = S+R)         */
+    const void* wp;        /* vqw_f16x3_pack_weights(out_w [Cin][S+R], K = Cin, M = S+R)     */
     const float* bias;     /* [S+R] or NULL                                                  */
     float* skip;           /* [B][S][T], accumulated in place                                */
     const float* net_in;   /* [B][R][T]                                                      */
     float* net_out;        /* [B][R][T]                                                      */
     void* net_out_planes;  /* [2][R/8][B*T][8] or NULL                                       */
-    int32_t B, T, R, S;
+    int32_t B, T, R, S;    /* S skip rows first, then R residual rows; either may be 0       */
     float w_scale_inv;
+    int32_t Cin;           /* contracted channels; 0 = R                                    */
+    int32_t xp_kc0, xp_KC; /* xp holds KC chunks per plane, the contraction starts at chunk kc0; KC 0 = Cin/8 */
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 

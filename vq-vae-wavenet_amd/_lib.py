@@ -58,7 +58,7 @@ class F16x3GateDesc(C.Structure):
         ('xp', _fp), ('wp', _fp), ('bias', _fp), ('cond', _fp), ('out0', _fp), ('save0', _fp), ('save1', _fp),
         ('out_planes', _fp), ('cond_bstride', C.c_int64),
         ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('ks', C.c_int32), ('dilation', C.c_int32),
-        ('cond_T', C.c_int32), ('w_scale_inv', C.c_float),
+        ('cond_T', C.c_int32), ('w_scale_inv', C.c_float), ('out_planes_kc0', C.c_int32), ('out_planes_KC', C.c_int32),
     ]
 
 
@@ -67,6 +67,7 @@ class F16x3OutDesc(C.Structure):
         ('xp', _fp), ('wp', _fp), ('bias', _fp), ('skip', _fp), ('net_in', _fp), ('net_out', _fp),
         ('net_out_planes', _fp),
         ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('S', C.c_int32), ('w_scale_inv', C.c_float),
+        ('Cin', C.c_int32), ('xp_kc0', C.c_int32), ('xp_KC', C.c_int32),
     ]
 
 _i, _f, _sz, _i64 = C.c_int, C.c_float, C.c_size_t, C.c_int64

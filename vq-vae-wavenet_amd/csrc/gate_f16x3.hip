@@ -114,6 +114,7 @@ struct LoopGeom {
     const void* wp;
     const void* xp;
     int M, Cin, ks, dilation, NB, m_row0, n0, t0;
+    int xKC, xkc0;   // chunks per plane of xp and the first chunk of this contraction (planes may hold more channels)
 };
 
 // acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: 16 accumulator tiles per wave, operands through
@@ -123,7 +124,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     const int KCA = g.ks * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
     const int nsteps = g.ks * spt;
     const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(g.wp, (unsigned)((size_t)2 * KCA * g.M * 16));
-    const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(g.xp, (unsigned)((size_t)2 * KCB * g.NB * 16));
+    const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(g.xp, (unsigned)((size_t)2 * g.xKC * g.NB * 16));
     // Stage image: 16 weight pieces (tile i, plane p at (i * 2 + p) KiB) then 16 activation pieces.  Wave wv moves
     // pieces wv*4 .. wv*4+3 of either kind; lane = (k half, row) as the MFMA wants it.
     int voffA[4], voffB[4], trow[4];
@@ -131,7 +132,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     for (int i = 0; i < 4; ++i) {
         const int q = wv * 4 + i, tile = q >> 1, p = q & 1;
         voffA[i] = ((p * KCA + lhi) * g.M + g.m_row0 + tile * 32 + l31) * 16;
-        voffB[i] = ((p * KCB + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
+        voffB[i] = ((p * g.xKC + g.xkc0 + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
         trow[i] = g.t0 + tile * 32 + l31;                    // time of this lane's activation row
     }
     f32x4 rg[PIECES];
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
     {
         LoopGeom g;
         g.wp = d.wp; g.xp = d.xp; g.M = 2 * R; g.Cin = R; g.ks = d.ks; g.dilation = d.dilation; g.NB = a.NB;
+        g.xKC = R / 8; g.xkc0 = 0;
         g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
         f16x3_mainloop(acc, smem, g, wv, lane);
     }
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
             if (d.out_planes) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    store_plane_quad(d.out_planes, R / 8, a.NB, 16 * mt + 4 * i + v4, n0 + 64 * wv + 32 * j + l31, lhi, gq[j]);
+                    store_plane_quad(d.out_planes, d.out_planes_KC > 0 ? d.out_planes_KC : R / 8, a.NB, d.out_planes_kc0 + 16 * mt + 4 * i + v4,
+                                     n0 + 64 * wv + 32 * j + l31, lhi, gq[j]);
             }
         }
 }
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const int R = d.R, S = d.S, T = d.T, M = S + R;
+    const int R = d.R, S = d.S, T = d.T, M = S + R;      // S skip rows, then R residual rows (either may be 0)
+    const int Cin = d.Cin > 0 ? d.Cin : R;
     const int n_mt = M / 256;
     const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
     f32x16 acc[8][2];
     {
         LoopGeom g;
-        g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = R; g.ks = 1; g.dilation = 1; g.NB = a.NB;
+        g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = Cin; g.ks = 1; g.dilation = 1; g.NB = a.NB;
+        g.xKC = d.xp_KC > 0 ? d.xp_KC : Cin / 8; g.xkc0 = d.xp_kc0;
         g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
         f16x3_mainloop(acc, smem, g, wv, lane);
     }
@@ -351,10 +356,13 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(dp, "vqw_f16x3_out_conv: null descriptor");
     const vqw_f16x3_out_desc& d = *dp;
-    VQW_CHECK(d.xp && d.wp && d.skip && d.net_in && d.net_out, "vqw_f16x3_out_conv: null operand");
+    VQW_CHECK(d.xp && d.wp, "vqw_f16x3_out_conv: null operand");
+    VQW_CHECK((d.S == 0 || d.skip) && (d.R == 0 || (d.net_in && d.net_out)), "vqw_f16x3_out_conv: null output");
     VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_out_conv: T must be a positive multiple of 256 (got %d)", d.T);
-    VQW_CHECK(d.R > 0 && d.R % 256 == 0 && d.S > 0 && d.S % 256 == 0, "vqw_f16x3_out_conv: R and S must be multiples of 256 (R=%d S=%d)", d.R, d.S);
-    VQW_CHECK((size_t)2 * (d.R / 8) * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_out_conv: activation planes exceed 2 GiB");
+    VQW_CHECK(d.R >= 0 && d.R % 256 == 0 && d.S >= 0 && d.S % 256 == 0 && d.S + d.R > 0, "vqw_f16x3_out_conv: R and S must be multiples of 256 (R=%d S=%d)", d.R, d.S);
+    const int cin = d.Cin > 0 ? d.Cin : d.R, xkc = d.xp_KC > 0 ? d.xp_KC : cin / 8;
+    VQW_CHECK(cin > 0 && cin % 16 == 0 && d.xp_kc0 >= 0 && d.xp_kc0 + cin / 8 <= xkc, "vqw_f16x3_out_conv: bad contraction range (Cin=%d kc0=%d KC=%d)", cin, d.xp_kc0, xkc);
+    VQW_CHECK((size_t)2 * xkc * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_out_conv: activation planes exceed 2 GiB");
     VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_out_conv: w_scale_inv must be positive");
     OutArgs a;
     a.d = d;
@@ -376,6 +384,9 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(d.R > 0 && d.R % 128 == 0, "vqw_f16x3_gate_conv: R must be a multiple of 128 (got %d)", d.R);
     VQW_CHECK(d.ks >= 1 && d.ks <= 8 && d.dilation >= 1, "vqw_f16x3_gate_conv: bad kernel size %d / dilation %d", d.ks, d.dilation);
     VQW_CHECK((size_t)2 * (d.R / 8) * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_gate_conv: activation planes exceed 2 GiB");
+    VQW_CHECK(d.out_planes_KC == 0 || (d.out_planes_kc0 >= 0 && d.out_planes_kc0 + d.R / 8 <= d.out_planes_KC &&
+                                       (size_t)2 * d.out_planes_KC * d.B * d.T * 16 < (size_t)1 << 31),
+              "vqw_f16x3_gate_conv: bad output plane range (kc0=%d KC=%d)", d.out_planes_kc0, d.out_planes_KC);
     VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_gate_conv: w_scale_inv must be positive");
     GateArgs a;
     a.d = d;

@@ -222,12 +222,17 @@ def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1):
     L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, L.stream()))
 
 
-def f16x3_out_conv(*, xp, wp, skip, net_in, net_out, B, T, R, S, w_scale_inv, bias=None, net_out_planes=None):
-    _need_planes(xp, 2 * B * R * T, 'xp')
-    _need_planes(wp, 2 * R * (S + R), 'wp')
-    _need(skip, B * S * T, 'skip')
-    _need(net_in, B * R * T, 'net_in')
-    _need(net_out, B * R * T, 'net_out')
+def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
+                   net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0):
+    cin = Cin if Cin > 0 else R
+    kc_all = xp_KC if xp_KC > 0 else cin // 8
+    _need_planes(xp, 2 * kc_all * 8 * B * T, 'xp')
+    _need_planes(wp, 2 * cin * (S + R), 'wp')
+    if S:
+        _need(skip, B * S * T, 'skip')
+    if R:
+        _need(net_in, B * R * T, 'net_in')
+        _need(net_out, B * R * T, 'net_out')
     if bias is not None:
         _need(bias, S + R, 'bias')
     if net_out_planes is not None:
@@ -235,15 +240,18 @@ def f16x3_out_conv(*, xp, wp, skip, net_in, net_out, B, T, R, S, w_scale_inv, bi
     d = L.F16x3OutDesc()
     d.xp, d.wp = xp.data_ptr(), wp.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
-    d.skip, d.net_in, d.net_out = skip.data_ptr(), net_in.data_ptr(), net_out.data_ptr()
+    d.skip = None if skip is None else skip.data_ptr()
+    d.net_in = None if net_in is None else net_in.data_ptr()
+    d.net_out = None if net_out is None else net_out.data_ptr()
     d.net_out_planes = None if net_out_planes is None else net_out_planes.data_ptr()
     d.B, d.T, d.R, d.S = B, T, R, S
+    d.Cin, d.xp_kc0, d.xp_KC = Cin, xp_kc0, xp_KC
     d.w_scale_inv = float(w_scale_inv)
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 
 
 def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,
-                    cond_bstride=0, save0=None, save1=None, out_planes=None):
+                    cond_bstride=0, save0=None, save1=None, out_planes=None, out_planes_kc0=0, out_planes_KC=0):
     _need_planes(xp, 2 * B * R * T, 'xp')
     _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
     _need(out0, B * R * T, 'out0')
@@ -264,8 +272,9 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     d.save0 = None if save0 is None else save0.data_ptr()
     d.save1 = None if save1 is None else save1.data_ptr()
     if out_planes is not None:
-        _need_planes(out_planes, 2 * B * R * T, 'out_planes')
+        _need_planes(out_planes, 2 * B * T * (out_planes_KC * 8 if out_planes_KC else R), 'out_planes')
     d.out_planes = None if out_planes is None else out_planes.data_ptr()
+    d.out_planes_kc0, d.out_planes_KC = out_planes_kc0, out_planes_KC
     d.cond_bstride = cond_bstride
     d.B, d.T, d.R, d.ks, d.dilation, d.cond_T = B, T, R, ks, dilation, cond_T
     d.w_scale_inv = float(w_scale_inv)

@@ -85,8 +85,10 @@ class VQVAE:
         self.overlap_wgrad = os.environ.get('VQW_OVERLAP', '1') != '0'   # decoder backward on two streams
         # experimental: the decoder's gate convs on the fp16 matrix pipe with two-plane operands
         # '1': gate convs; '2': gate convs + the 1x1 skip/residual convs (which then hand over the next layer's planes)
-        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2')
-        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '2'
+        # '3': as '2', but the skip path of all layers as ONE contraction over the gated planes kept side by side
+        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2', '3')
+        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('2', '3')
+        self.skip_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '3'
         self._side = None
         self._build_layout()
         self._init_params(seed)
@@ -299,7 +301,10 @@ class VQVAE:
             ws['xp'] = torch.empty(2 * B * R * T, dtype=torch.float16, device=dev)
             ws['wp_all'] = torch.empty(L, 2 * self.ks * R * 2 * R, dtype=torch.float16, device=dev)
             ws['wp'] = [ws['wp_all'][l] for l in range(L)]
-            ws['gp'] = torch.empty(2 * B * R * T, dtype=torch.float16, device=dev)
+            ws['gp'] = torch.empty(2 * B * R * T * (L if self.skip_f16x3 else 1), dtype=torch.float16, device=dev)
+            if self.skip_f16x3:
+                ws['wskip'] = torch.empty(2 * L * R * S, dtype=torch.float16, device=dev)
+                ws['wres'] = torch.empty(L, 2 * R * R, dtype=torch.float16, device=dev)
             ws['wop_all'] = torch.empty(L, 2 * R * (S + R), dtype=torch.float16, device=dev)
             ws['wop'] = [ws['wop_all'][l] for l in range(L)]
         ws['h1'] = e(B, S, T)
@@ -397,10 +402,14 @@ class VQVAE:
         # fp16x3 needs whole 256-step tiles inside a batch row, 128-channel blocks and one condition frame per 32 steps;
         # |w| < 255 and |net| < 65504 (fp16 range of the leading planes) are assumed, not checked
         f16x3 = self.gate_f16x3 and T % 256 == 0 and R % 128 == 0 and (T // Tz) % 32 == 0
+        f16x3_skip = f16x3 and self.skip_f16x3 and R % 256 == 0 and S % 256 == 0 and 2 * L * R * B * T * 2 < (1 << 31)
         f16x3_out = f16x3 and self.out_f16x3 and R % 256 == 0 and S % 256 == 0    # the 1x1 skip + residual conv too; it hands the next layer its planes
         if f16x3:      # this step's weights of all layers as fp16 planes, one launch per kind
             K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, 256.0, count=L)
-            if f16x3_out:
+            if f16x3_skip:     # [L*R][S] skip kernels of all layers as one K = L*R operand; the residual kernels per layer
+                K.f16x3_pack_weights(P['out_w'], ws['wskip'], L * R, S, S + R, 256.0)
+                K.f16x3_pack_weights(P['out_w'].view(-1)[S:], ws['wres'], R, R, S + R, 256.0, count=L)
+            elif f16x3_out:
                 K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, 256.0, count=L)
         for l, d in enumerate(self.dil):
             if f16x3:
@@ -409,8 +418,13 @@ class VQVAE:
                 K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if save else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
                                   cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T=T, R=R, ks=self.ks,
-                                  dilation=d, w_scale_inv=1.0 / 256.0, out_planes=ws['gp'] if f16x3_out else None)
-                if f16x3_out:
+                                  dilation=d, w_scale_inv=1.0 / 256.0, out_planes=ws['gp'] if f16x3_out else None,
+                                  out_planes_kc0=l * (R // 8) if f16x3_skip else 0, out_planes_KC=L * (R // 8) if f16x3_skip else 0)
+                if f16x3_skip:   # residual half now; the skip half of all layers after the loop
+                    K.f16x3_out_conv(xp=ws['gp'], xp_kc0=l * (R // 8), xp_KC=L * (R // 8), Cin=R, wp=ws['wres'][l],
+                                     bias=P['out_b'][l][S:], net_in=net[l], net_out=net[l + 1], net_out_planes=ws['xp'],
+                                     B=B, T=T, R=R, S=0, w_scale_inv=1.0 / 256.0)
+                elif f16x3_out:
                     K.f16x3_out_conv(xp=ws['gp'], wp=ws['wop'][l], bias=P['out_b'][l], skip=ws['skip'], net_in=net[l],
                                      net_out=net[l + 1], net_out_planes=ws['xp'], B=B, T=T, R=R, S=S, w_scale_inv=1.0 / 256.0)
                 else:
@@ -426,6 +440,9 @@ class VQVAE:
             K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
                         aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
                         epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])                                       # :132-136, wavenet.py:72-73
+        if f16x3_skip:   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
+            K.f16x3_out_conv(xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
+                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / 256.0)
         K.conv_gemm(x0=ws['skip'], in_relu=True, w=P['post1_w'], bias=P['post1_b'], out0=ws['h1'],
                     cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T, M=S,
                     C0=S, taps=[0])                                                       # wavenet.py:80-88
