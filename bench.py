@@ -185,6 +185,7 @@ def main():
                     "'2019' needs --length 6400 (T %% 320 == 0): BASELINE.json configs[4] in fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
+    ap.add_argument('--no-experimental', action='store_true', help='skip the extra timing of the opt-in fp16x3 forward path')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 code path)")
     a = ap.parse_args()
 
@@ -245,6 +246,30 @@ def main():
     loss = model.losses(ws)[0]
     log('train: %.2f ms/step, loss %.5f' % (dt / a.steps * 1e3, loss))
 
+    # Reported beside the headline, never as it: the same step with the opt-in fp16x3 forward convs
+    exp = None
+    if world == 1 and not a.no_experimental and os.environ.get('VQW_GATE_F16X3', '0') == '0':
+        os.environ['VQW_GATE_F16X3'] = '3'
+        try:
+            model_x = pkg.model.VQVAE(m, w, S, device=dev, seed=0)
+        finally:
+            os.environ['VQW_GATE_F16X3'] = '0'
+        for _ in range(a.warmup):
+            model_x.train_step(x, spk)
+        torch.cuda.synchronize()
+        tx = time.perf_counter()
+        for _ in range(a.steps):
+            ws_x = model_x.train_step(x, spk)
+        torch.cuda.synchronize()
+        dtx = time.perf_counter() - tx
+        exp = {"switch": "VQW_GATE_F16X3=3", "what": "decoder forward gate / residual / skip convs as fp32-accurate 3-term contractions "
+               "of two-plane fp16 operands on the fp16 matrix pipe (parity tests at the fp32 path's tolerances); backward unchanged",
+               "value": B * T * a.steps / dtx, "unit": "audio-samples/s", "ms_per_step": dtx / a.steps * 1e3,
+               "loss": model_x.losses(ws_x)[0]}
+        log('experimental fp16x3 forward: %.2f ms/step, loss %.5f' % (exp["ms_per_step"], exp["loss"]))
+        del model_x, ws_x
+        torch.cuda.empty_cache()
+
     gen = None
     if not a.no_gen:
         gen_mod = pkg.generator
@@ -304,6 +329,8 @@ def main():
             rec["roofline"].update({"kernel": "gate_f16x3_kernel (experimental; dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate on the fp16 matrix pipe)",
                                     "achieved": 3 * ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * ach / PEAK_F16_MFMA_TFLOPS,
                                     "fp32_equivalent_tflops": ach, "flop_per_launch": 3 * flops_gate, "traffic": None})
+        if exp:
+            rec["experimental_f16x3"] = exp
         if gen:
             rec["ar_gen"] = gen
         if world == 1 and not a.no_cpu_baseline:
