@@ -13,8 +13,8 @@
 //
 // Block = 256 output channels (128 filter + the 128 matching gate channels, so tanh * sigmoid meets in one lane)
 // x 256 time steps; four waves, each all 256 channels x 64 time steps (16 accumulator tiles in AGPRs); K step = 16
-// input channels of one tap; operands through VGPRs into a 4-stage LDS ring (requested three steps ahead, written
-// one step ahead, one barrier per step).
+// input channels of one tap; operands through VGPRs into a 4-stage LDS ring, MFMA fragments double-buffered in
+// registers (read from LDS one step ahead), one barrier per step.
 #include "vqw_common.h"
 
 namespace {
@@ -118,7 +118,7 @@ struct LoopGeom {
 };
 
 // acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: 16 accumulator tiles per wave, operands through
-// VGPRs into the 4-stage LDS ring (requested three K steps ahead, written one step ahead, one barrier per step).
+// VGPRs into the 4-stage LDS ring, fragments double-buffered in registers, one barrier per step.
 __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, const LoopGeom& g, int wv, int lane) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const int KCA = g.ks * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
@@ -135,6 +135,9 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
         voffB[i] = ((p * g.xKC + g.xkc0 + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
         trow[i] = g.t0 + tile * 32 + l31;                    // time of this lane's activation row
     }
+    // Software pipeline of one step s (one barrier): the MFMAs run on the fragments of stage s, which were read from
+    // LDS during step s - 1; meanwhile the fragments of stage s + 1 are read into the other fragment set; behind the
+    // MFMAs stage s + 2 (requested from global memory one step ago) is written to LDS and stage s + 3 is requested.
     f32x4 rg[PIECES];
     auto rissue = [&](int s) {
         const int j = s / spt, kc = (s - j * spt) * 2;
@@ -154,6 +157,18 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
             *reinterpret_cast<f32x4*>(dst + 16 * 1024 + i * 1024) = rg[4 + i];
         }
     };
+    struct Frags { uint4 a[8][2], b[2][2]; };
+    auto read_frags = [&](Frags& f, int s) {
+        const char* st = smem + (s % NSTG) * STG_BYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) f.a[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) f.b[j][p] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + p) * 1024);
+    };
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -161,31 +176,29 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    Frags f0, f1;
     rissue(0); rcommit(0);
-    if (nsteps > 1) { rissue(1); rcommit(1); }
-    if (nsteps > 2) rissue(2);
-    for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stages <= s + 1 are in LDS, stage s - 2's buffer is free
-        if (s + 2 < nsteps) rcommit(s + 2);
-        if (s + 3 < nsteps) rissue(s + 3);
-        const char* st = smem + (s % NSTG) * STG_BYTES + lane * 16;
-        uint4 af[8][2], bf[2][2];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) af[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + p) * 1024);
+    rissue(1); rcommit(1);
+    rissue(2);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    read_frags(f0, 0);
+    auto step = [&](const Frags& cur, Frags& nxt, int s) {   // nsteps is even (Cin % 32 == 0 is checked by the callers)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage s + 1 is in LDS, every wave holds its fragments of stage s
+        if (s + 1 < nsteps) read_frags(nxt, s + 1);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {   // small terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[j][1]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][1]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][0]), __builtin_bit_cast(f16x8, cur.b[j][1]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][1]), __builtin_bit_cast(f16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][0]), __builtin_bit_cast(f16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
             }
+        if (s + 2 < nsteps) rcommit(s + 2);
+        if (s + 3 < nsteps) rissue(s + 3);
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(f0, f1, s);
+        step(f1, f0, s + 1);
     }
 }
 
@@ -361,7 +374,7 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_out_conv: T must be a positive multiple of 256 (got %d)", d.T);
     VQW_CHECK(d.R >= 0 && d.R % 256 == 0 && d.S >= 0 && d.S % 256 == 0 && d.S + d.R > 0, "vqw_f16x3_out_conv: R and S must be multiples of 256 (R=%d S=%d)", d.R, d.S);
     const int cin = d.Cin > 0 ? d.Cin : d.R, xkc = d.xp_KC > 0 ? d.xp_KC : cin / 8;
-    VQW_CHECK(cin > 0 && cin % 16 == 0 && d.xp_kc0 >= 0 && d.xp_kc0 + cin / 8 <= xkc, "vqw_f16x3_out_conv: bad contraction range (Cin=%d kc0=%d KC=%d)", cin, d.xp_kc0, xkc);
+    VQW_CHECK(cin >= 64 && cin % 32 == 0 && d.xp_kc0 >= 0 && d.xp_kc0 + cin / 8 <= xkc, "vqw_f16x3_out_conv: bad contraction range (Cin=%d kc0=%d KC=%d)", cin, d.xp_kc0, xkc);
     VQW_CHECK((size_t)2 * xkc * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_out_conv: activation planes exceed 2 GiB");
     VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_out_conv: w_scale_inv must be positive");
     OutArgs a;
