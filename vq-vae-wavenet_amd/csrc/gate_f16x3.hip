@@ -235,40 +235,49 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
         f16x3_mainloop(acc, smem, g, wv, lane);
     }
 
-    // ---- epilogue: + bias + upsampled condition (add_condition, wavenet_ops.py:93-101), tanh(filter) * sigmoid(gate)
-    const float* cb = d.cond ? d.cond + (size_t)b * d.cond_bstride : nullptr;
+    // ---- epilogue: + bias + upsampled condition (add_condition, wavenet_ops.py:93-101), tanh(filter) * sigmoid(gate).
+    // With one block per CU nothing overlaps it, so it is kept lean: one 64-bit row offset per four channels, 32-bit
+    // offsets inside, v_rcp_f32 instead of IEEE divisions (1 ulp; the quotients feed tanh/sigmoid values in [-1, 1]).
+    const bool hb = d.bias != nullptr, hc = d.cond != nullptr;
+    const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);      // absent operands read a valid dummy address
+    const float* cb = hc ? d.cond + (size_t)b * d.cond_bstride : reinterpret_cast<const float*>(d.wp);
+    const int tcol = t0 + 64 * wv + l31;
+    const int tz0 = (t0 + 64 * wv) / a.ratio, tz1 = (t0 + 64 * wv + 32) / a.ratio;   // 32 | ratio: one frame per tile row
+    const bool s0 = d.save0 != nullptr, s1 = d.save1 != nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) {
+            const int c0 = 128 * mt + 32 * i + 8 * v4 + 4 * lhi;         // first of this lane's four channels
             float addf[4][2], addg[4][2];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int c = 128 * mt + 32 * i + 8 * v4 + 4 * lhi + e;
-                const float bfv = d.bias ? d.bias[c] : 0.0f, bgv = d.bias ? d.bias[R + c] : 0.0f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int tz = (t0 + 64 * wv + 32 * j) / a.ratio;    // 32 | ratio: one frame per tile row
-                    addf[e][j] = bfv + (cb ? cb[(size_t)c * d.cond_T + tz] : 0.0f);
-                    addg[e][j] = bgv + (cb ? cb[(size_t)(R + c) * d.cond_T + tz] : 0.0f);
-                }
+                const float bfv = bp[hb ? c0 + e : 0], bgv = bp[hb ? R + c0 + e : 0];
+                const int cf = (c0 + e) * d.cond_T, cg = (R + c0 + e) * d.cond_T;
+                const float f0 = cb[hc ? cf + tz0 : 0], f1 = cb[hc ? cf + tz1 : 0];
+                const float g0 = cb[hc ? cg + tz0 : 0], g1 = cb[hc ? cg + tz1 : 0];
+                addf[e][0] = (hb ? bfv : 0.0f) + (hc ? f0 : 0.0f); addf[e][1] = (hb ? bfv : 0.0f) + (hc ? f1 : 0.0f);
+                addg[e][0] = (hb ? bgv : 0.0f) + (hc ? g0 : 0.0f); addg[e][1] = (hb ? bgv : 0.0f) + (hc ? g1 : 0.0f);
             }
+            const size_t off = ((size_t)b * R + c0) * T + tcol;
+            float* po = d.out0 + off;
+            float* p0 = s0 ? d.save0 + off : po;
+            float* p1 = s1 ? d.save1 + off : po;
             float gq[2][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 128 * mt + 32 * i + 8 * v4 + 4 * lhi + e;
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int t = t0 + 64 * wv + 32 * j + l31;
-                    const float th = tanh_f(acc[i][j][v4 * 4 + e] * d.w_scale_inv + addf[e][j]);
-                    const float sg = sigmoid_f(acc[i + 4][j][v4 * 4 + e] * d.w_scale_inv + addg[e][j]);
-                    const size_t o = ((size_t)b * R + c) * T + t;
+                    const float xf = acc[i][j][v4 * 4 + e] * d.w_scale_inv + addf[e][j];
+                    const float xg = acc[i + 4][j][v4 * 4 + e] * d.w_scale_inv + addg[e][j];
+                    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * xf) + 1.0f);
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-xg));
+                    const int o = e * T + 32 * j;
                     gq[j][e] = th * sg;
-                    d.out0[o] = gq[j][e];
-                    if (d.save0) d.save0[o] = th;
-                    if (d.save1) d.save1[o] = sg;
+                    if (s0) p0[o] = th;
+                    if (s1) p1[o] = sg;
+                    po[o] = gq[j][e];
                 }
-            }
             if (d.out_planes) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -299,29 +308,31 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
         f16x3_mainloop(acc, smem, g, wv, lane);
     }
     const bool is_skip = mt * 256 < S;    // 256 | S: a block is all skip rows or all residual rows
+    const bool hb = d.bias != nullptr;
+    const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);
+    const int tcol = t0 + 64 * wv + l31;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) {
             const int m0 = mt * 256 + 32 * i + 8 * v4 + 4 * lhi;     // first of this lane's four rows
+            const size_t off = is_skip ? ((size_t)b * S + m0) * T + tcol : ((size_t)b * R + (m0 - S)) * T + tcol;
+            const float* pin = is_skip ? d.skip + off : d.net_in + off;
+            float* pout = is_skip ? d.skip + off : d.net_out + off;
             float bq[4], old[2][4], nq[2][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                bq[e] = d.bias ? d.bias[m0 + e] : 0.0f;
+                const float bv = bp[hb ? m0 + e : 0];
+                bq[e] = hb ? bv : 0.0f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int t = t0 + 64 * wv + 32 * j + l31;
-                    old[j][e] = is_skip ? d.skip[((size_t)b * S + m0 + e) * T + t] : d.net_in[((size_t)b * R + (m0 - S) + e) * T + t];
-                }
+                for (int j = 0; j < 2; ++j) old[j][e] = pin[e * T + 32 * j];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int t = t0 + 64 * wv + 32 * j + l31;
                     nq[j][e] = old[j][e] + (acc[i][j][v4 * 4 + e] * d.w_scale_inv + bq[e]);
-                    if (is_skip) d.skip[((size_t)b * S + m0 + e) * T + t] = nq[j][e];
-                    else d.net_out[((size_t)b * R + (m0 - S) + e) * T + t] = nq[j][e];
+                    pout[e * T + 32 * j] = nq[j][e];
                 }
             if (!is_skip && d.net_out_planes) {
 #pragma unroll
