@@ -298,8 +298,9 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
  * fp32 accumulators (DESIGN.md 3.2b for the error analysis and measurements).
  * Plane layout: [plane 0..1][channel chunk of 8][row][8 fp16] (16-byte entries); 2 * rows * channels bytes each.    */
 
-/* x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0 */
-int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, vqw_stream_t s);
+/* scale * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0.  scale: 1 for activations, a power of two
+ * that lifts a gradient tensor into fp16's range (undone through w_scale_inv of the consumer) */
+int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, vqw_stream_t s);
 /* w [ks][R][ldw] fp32 (kernel[k, Cin, Cout]: filter columns 0..R-1, gate columns R..2R-1), multiplied by `scale`
  * (a power of two that lifts the residual plane into fp16's normal range, e.g. 256) -> planes [2][ks*R/8][2R][8]
  * with the output channels in the kernel's block order; R % 128 == 0.  `count` layers stored back to back (w: ks*R*ldw
@@ -345,6 +346,9 @@ typedef struct vqw_f16x3_out_desc {
     float w_scale_inv;
     int32_t Cin;           /* contracted channels; 0 = R                                    */
     int32_t xp_kc0, xp_KC; /* xp holds KC chunks per plane, the contraction starts at chunk kc0; KC 0 = Cin/8 */
+    int32_t ks, dilation;  /* taps (0 = 1): wp = [ks*Cin][S+R], tap j reads x[t - dir*(ks-1-j)*dilation]          */
+    int32_t dir;           /* >= 0: causal conv; < 0: reads ahead = the input gradient of a causal conv with
+                            * transposed kernels (net_in = the gradient arriving from the residual path or NULL) */
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 

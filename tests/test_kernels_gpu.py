@@ -401,6 +401,36 @@ def test_out_conv_f16x3_matches_fp32_engine(K, B, T):
     assert torch.equal(np_.view(torch.int16), np_ref.view(torch.int16)), 'net planes differ from a split of net_out'
 
 
+@pytest.mark.parametrize('B,T,d,top', [(2, 512, 3, False), (2, 768, 300, True), (8, 6656, 16, False)])
+def test_dgrad_f16x3_matches_fp32_engine(K, B, T, d, top):
+    """Experimental input gradient of the gate conv (reads AHEAD: x[t + (ks-1-j) d], zero behind the end of a batch row)
+    with the gradient operand lifted by 2^20 into fp16 planes: against the fp32 engine's dgrad launch on the same
+    tiny-magnitude inputs (relative 2e-5 of the tensor max)."""
+    Rr, ks = 256, 3
+    gen = torch.Generator().manual_seed(5 + T + d)
+    dpre = (torch.randn(B, 2 * Rr, T, generator=gen) * 3e-6).to(DEV)
+    wt = (torch.randn(ks, 2 * Rr, Rr, generator=gen) * 0.05).to(DEV)
+    dnet = (torch.randn(B, Rr, T, generator=gen) * 1e-5).to(DEV)
+    taps_b = [(ks - 1 - j) * d for j in range(ks)]
+    ref = torch.empty(B, Rr, T, device=DEV)
+    if top:
+        K.conv_gemm(x0=dpre, w=wt, out0=ref, B=B, T_in=T, T_out=T, M=Rr, C0=2 * Rr, taps=taps_b)
+    else:
+        K.conv_gemm(x0=dpre, w=wt, out1=ref, aux1=dnet, out0=ref, B=B, T_in=T, T_out=T, M=Rr, M0=0, C0=2 * Rr, taps=taps_b,
+                    epilogue=K.EPI_ACCUM_SPLIT)
+    GS = float(2 ** 20)
+    dp = torch.empty(2 * B * 2 * Rr * T, dtype=torch.float16, device=DEV)
+    wp = torch.empty(2 * ks * 2 * Rr * Rr, dtype=torch.float16, device=DEV)
+    out = torch.empty_like(ref)
+    K.f16x3_split_activations(dpre, dp, B, 2 * Rr, T, scale=GS)
+    K.f16x3_pack_weights(wt, wp, ks * 2 * Rr, Rr, Rr, 256.0)
+    K.f16x3_out_conv(xp=dp, Cin=2 * Rr, ks=ks, dilation=d, direction=-1, wp=wp, net_in=None if top else dnet, net_out=out,
+                     B=B, T=T, R=Rr, S=0, w_scale_inv=1.0 / (256.0 * GS))
+    assert torch.isfinite(out).all()
+    err = float((out - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-5, 'input gradient differs from the fp32 engine by %.3e of max' % err
+
+
 def test_accum_split_and_two_sources(K):
     B, T, Cg, S, Rr = 2, 512, 32, 64, 32
     gated, w, b = rnd(B, T, Cg, seed=1), rnd(Cg, S + Rr, seed=2, s=0.2), rnd(S + Rr, seed=3)

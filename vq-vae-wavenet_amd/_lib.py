@@ -68,6 +68,7 @@ class F16x3OutDesc(C.Structure):
         ('net_out_planes', _fp),
         ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('S', C.c_int32), ('w_scale_inv', C.c_float),
         ('Cin', C.c_int32), ('xp_kc0', C.c_int32), ('xp_KC', C.c_int32),
+        ('ks', C.c_int32), ('dilation', C.c_int32), ('dir', C.c_int32),
     ]
 
 _i, _f, _sz, _i64 = C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -108,7 +109,7 @@ SIGNATURES = {
     'vqw_ar_decode_run_async': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     'vqw_ar_decode_wait': (_i, [_fp]),
     'vqw_ar_decode_destroy': (_i, [_fp]),
-    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _fp]),
+    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _fp]),
     'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),
     'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),

@@ -42,7 +42,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& p0, uint4& p1
 }
 
 // x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16
-__global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T) {
+__global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T, float scale) {
     const size_t NB = (size_t)B * T;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NB * (C / 8)) return;
@@ -51,7 +51,7 @@ __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict_
     const int b = (int)(row / T), t = (int)(row % T);
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = x[((size_t)b * C + kc * 8 + e) * T + t];
+    for (int e = 0; e < 8; ++e) v[e] = x[((size_t)b * C + kc * 8 + e) * T + t] * scale;
     uint4 p0, p1;
     split8(v, p0, p1);
     planes[(size_t)kc * NB + row] = p0;
@@ -115,6 +115,7 @@ struct LoopGeom {
     const void* xp;
     int M, Cin, ks, dilation, NB, m_row0, n0, t0;
     int xKC, xkc0;   // chunks per plane of xp and the first chunk of this contraction (planes may hold more channels)
+    int dir, T;      // dir > 0: tap j reads x[t - (ks-1-j) d] (causal conv); dir < 0: x[t + (ks-1-j) d] (its input gradient)
 };
 
 // acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: 16 accumulator tiles per wave, operands through
@@ -141,11 +142,12 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     f32x4 rg[PIECES];
     auto rissue = [&](int s) {
         const int j = s / spt, kc = (s - j * spt) * 2;
-        const int shift = (g.ks - 1 - j) * g.dilation;       // tap j reads x[t - (ks-1-j) d]
+        const int shift = (g.ks - 1 - j) * g.dilation * (g.dir < 0 ? -1 : 1);   // rows before / behind the batch row read as zero
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * g.M * 16, 0);
-            const int vb = (trow[i] >= shift) ? voffB[i] + (kc * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
+            const int tr = trow[i] - shift;
+            const int vb = (tr >= 0 && tr < g.T) ? voffB[i] + (kc * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
             rg[4 + i] = vqw_buf_load4(rb, vb, 0);
         }
     };
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
     {
         LoopGeom g;
         g.wp = d.wp; g.xp = d.xp; g.M = 2 * R; g.Cin = R; g.ks = d.ks; g.dilation = d.dilation; g.NB = a.NB;
-        g.xKC = R / 8; g.xkc0 = 0;
+        g.xKC = R / 8; g.xkc0 = 0; g.dir = 1; g.T = T;
         g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
         f16x3_mainloop(acc, smem, g, wv, lane);
     }
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
     f32x16 acc[8][2];
     {
         LoopGeom g;
-        g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = Cin; g.ks = 1; g.dilation = 1; g.NB = a.NB;
-        g.xKC = d.xp_KC > 0 ? d.xp_KC : Cin / 8; g.xkc0 = d.xp_kc0;
+        g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = Cin; g.ks = d.ks > 0 ? d.ks : 1; g.dilation = d.dilation > 0 ? d.dilation : 1; g.NB = a.NB;
+        g.xKC = d.xp_KC > 0 ? d.xp_KC : Cin / 8; g.xkc0 = d.xp_kc0; g.dir = d.dir < 0 ? -1 : 1; g.T = T;
         g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
         f16x3_mainloop(acc, smem, g, wv, lane);
     }
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
         for (int v4 = 0; v4 < 4; ++v4) {
             const int m0 = mt * 256 + 32 * i + 8 * v4 + 4 * lhi;     // first of this lane's four rows
             const size_t off = is_skip ? ((size_t)b * S + m0) * T + tcol : ((size_t)b * R + (m0 - S)) * T + tcol;
-            const float* pin = is_skip ? d.skip + off : d.net_in + off;
+            const bool hin = is_skip || d.net_in != nullptr;
+            const float* pin = is_skip ? d.skip + off : (d.net_in ? d.net_in + off : d.net_out + off);
             float* pout = is_skip ? d.skip + off : d.net_out + off;
             float bq[4], old[2][4], nq[2][4];
 #pragma unroll
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
                 const float bv = bp[hb ? m0 + e : 0];
                 bq[e] = hb ? bv : 0.0f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) old[j][e] = pin[e * T + 32 * j];
+                for (int j = 0; j < 2; ++j) { const float ov = pin[e * T + 32 * j]; old[j][e] = hin ? ov : 0.0f; }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -346,12 +349,12 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
 
 extern "C" {
 
-int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, vqw_stream_t s_) {
+int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(x && planes, "vqw_f16x3_split_activations: null pointer");
     VQW_CHECK(B > 0 && T > 0 && C > 0 && C % 8 == 0, "vqw_f16x3_split_activations: C must be a positive multiple of 8 (got %d)", C);
     const size_t n = (size_t)B * T * (C / 8);
-    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T);
+    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale);
     VQW_LAUNCH_CHECK("vqw_f16x3_split_activations");
     return 0;
 }
@@ -381,11 +384,12 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(dp, "vqw_f16x3_out_conv: null descriptor");
     const vqw_f16x3_out_desc& d = *dp;
     VQW_CHECK(d.xp && d.wp, "vqw_f16x3_out_conv: null operand");
-    VQW_CHECK((d.S == 0 || d.skip) && (d.R == 0 || (d.net_in && d.net_out)), "vqw_f16x3_out_conv: null output");
+    VQW_CHECK((d.S == 0 || d.skip) && (d.R == 0 || d.net_out), "vqw_f16x3_out_conv: null output");
+    VQW_CHECK(d.ks >= 0 && d.ks <= 8 && d.dilation >= 0, "vqw_f16x3_out_conv: bad kernel size %d / dilation %d", d.ks, d.dilation);
     VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_out_conv: T must be a positive multiple of 256 (got %d)", d.T);
     VQW_CHECK(d.R >= 0 && d.R % 256 == 0 && d.S >= 0 && d.S % 256 == 0 && d.S + d.R > 0, "vqw_f16x3_out_conv: R and S must be multiples of 256 (R=%d S=%d)", d.R, d.S);
     const int cin = d.Cin > 0 ? d.Cin : d.R, xkc = d.xp_KC > 0 ? d.xp_KC : cin / 8;
-    VQW_CHECK(cin >= 64 && cin % 32 == 0 && d.xp_kc0 >= 0 && d.xp_kc0 + cin / 8 <= xkc, "vqw_f16x3_out_conv: bad contraction range (Cin=%d kc0=%d KC=%d)", cin, d.xp_kc0, xkc);
+    VQW_CHECK(cin >= 64 && cin % 32 == 0 && d.xp_kc0 >= 0 && d.xp_kc0 + cin / 8 <= xkc && (d.ks <= 1 || d.xp_kc0 == 0), "vqw_f16x3_out_conv: bad contraction range (Cin=%d kc0=%d KC=%d)", cin, d.xp_kc0, xkc);
     VQW_CHECK((size_t)2 * xkc * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_out_conv: activation planes exceed 2 GiB");
     VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_out_conv: w_scale_inv must be positive");
     OutArgs a;

@@ -201,11 +201,11 @@ def _need_planes(t, n_halves, what):
     L.require_cuda(t)
 
 
-def f16x3_split_activations(x, planes, B, Cc, T):
-    """x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16."""
+def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0):
+    """scale * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16."""
     _need(x, B * Cc * T, 'x')
     _need_planes(planes, 2 * B * Cc * T, 'planes')
-    L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, L.stream()))
+    L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, float(scale), L.stream()))
 
 
 def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1):
@@ -223,15 +223,16 @@ def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1):
 
 
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
-                   net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0):
+                   net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1):
     cin = Cin if Cin > 0 else R
     kc_all = xp_KC if xp_KC > 0 else cin // 8
     _need_planes(xp, 2 * kc_all * 8 * B * T, 'xp')
-    _need_planes(wp, 2 * cin * (S + R), 'wp')
+    _need_planes(wp, 2 * ks * cin * (S + R), 'wp')
     if S:
         _need(skip, B * S * T, 'skip')
     if R:
-        _need(net_in, B * R * T, 'net_in')
+        if net_in is not None:
+            _need(net_in, B * R * T, 'net_in')
         _need(net_out, B * R * T, 'net_out')
     if bias is not None:
         _need(bias, S + R, 'bias')
@@ -246,6 +247,7 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     d.net_out_planes = None if net_out_planes is None else net_out_planes.data_ptr()
     d.B, d.T, d.R, d.S = B, T, R, S
     d.Cin, d.xp_kc0, d.xp_KC = Cin, xp_kc0, xp_KC
+    d.ks, d.dilation, d.dir = ks, dilation, direction
     d.w_scale_inv = float(w_scale_inv)
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 

@@ -86,9 +86,11 @@ class VQVAE:
         # experimental: the decoder's gate convs on the fp16 matrix pipe with two-plane operands
         # '1': gate convs; '2': gate convs + the 1x1 skip/residual convs (which then hand over the next layer's planes)
         # '3': as '2', but the skip path of all layers as ONE contraction over the gated planes kept side by side
-        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2', '3')
-        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('2', '3')
-        self.skip_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '3'
+        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2', '3', '4')
+        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('2', '3', '4')
+        # '4': as '3', and the gate convs' input gradient (backward) with the gradient operand lifted by 2^20
+        self.skip_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('3', '4')
+        self.dgrad_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '4'
         self._side = None
         self._build_layout()
         self._init_params(seed)
@@ -302,6 +304,9 @@ class VQVAE:
             ws['wp_all'] = torch.empty(L, 2 * self.ks * R * 2 * R, dtype=torch.float16, device=dev)
             ws['wp'] = [ws['wp_all'][l] for l in range(L)]
             ws['gp'] = torch.empty(2 * B * R * T * (L if self.skip_f16x3 else 1), dtype=torch.float16, device=dev)
+            if self.dgrad_f16x3:
+                ws['dp'] = torch.empty(2 * B * 2 * R * T, dtype=torch.float16, device=dev)
+                ws['wdg'] = torch.empty(L, 2 * self.ks * 2 * R * R, dtype=torch.float16, device=dev)
             if self.skip_f16x3:
                 ws['wskip'] = torch.empty(2 * L * R * S, dtype=torch.float16, device=dev)
                 ws['wres'] = torch.empty(L, 2 * R * R, dtype=torch.float16, device=dev)
@@ -525,6 +530,12 @@ class VQVAE:
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
         dnet_ring, dpre_ring = ws['dnet_ring'], ws['dpre_ring']
+        # Experimental: the gate convs' input gradient on the fp16 matrix pipe.  d(loss)/d(logits) is bounded by 1 / (B T), the
+        # gradient operand is lifted by 2^20 before it is split into fp16 planes (|dpre| < 0.06 assumed, not checked).
+        dgrad_x3 = self.dgrad_f16x3 and T % 256 == 0 and R % 256 == 0
+        GS = float(2 ** 20)
+        if dgrad_x3:
+            K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, 256.0, count=L)
         side_done = {}
         dnet = dnet_ring[(L - 1) % 3]
         for l in range(L - 1, -1, -1):
@@ -541,7 +552,12 @@ class VQVAE:
                 ready = torch.cuda.Event()
                 ready.record(main)
             taps_b = [(ks - 1 - j) * d for j in range(ks)]
-            if top:
+            if dgrad_x3:
+                K.f16x3_split_activations(dpre, ws['dp'], B, 2 * R, T, scale=GS)
+                K.f16x3_out_conv(xp=ws['dp'], Cin=2 * R, ks=ks, dilation=d, direction=-1, wp=ws['wdg'][l],
+                                 net_in=None if top else dnet, net_out=dnet_next, B=B, T=T, R=R, S=0,
+                                 w_scale_inv=1.0 / (256.0 * GS))
+            elif top:
                 K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
                             tile=self.tiles['dgrad'])
             else:
