@@ -300,7 +300,8 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
 
 /* scale * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0.  scale: 1 for activations, a power of two
  * that lifts a gradient tensor into fp16's range (undone through w_scale_inv of the consumer) */
-int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, vqw_stream_t s);
+int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC,
+                                vqw_stream_t s);   /* planes hold KC chunks per plane, x goes to chunks kc0.. (0, 0: KC = C/8) */
 /* w [ks][R][ldw] fp32 (kernel[k, Cin, Cout]: filter columns 0..R-1, gate columns R..2R-1), multiplied by `scale`
  * (a power of two that lifts the residual plane into fp16's normal range, e.g. 256) -> planes [2][ks*R/8][2R][8]
  * with the output channels in the kernel's block order; R % 128 == 0.  `count` layers stored back to back (w: ks*R*ldw
@@ -349,6 +350,12 @@ typedef struct vqw_f16x3_out_desc {
     int32_t ks, dilation;  /* taps (0 = 1): wp = [ks*Cin][S+R], tap j reads x[t - dir*(ks-1-j)*dilation]          */
     int32_t dir;           /* >= 0: causal conv; < 0: reads ahead = the input gradient of a causal conv with
                             * transposed kernels (net_in = the gradient arriving from the residual path or NULL) */
+    int32_t planes_kc0, planes_KC; /* placement of net_out_planes (0, 0: R/8 chunks, or 2R/8 for epi 1)         */
+    float plane_scale;     /* net_out_planes hold plane_scale * net_out (0 = 1): gradients are lifted by a power of two */
+    int32_t epi;           /* 0: as described above.  1: gate backward -- S = 0, dg = W^T x over Cin gradient channels,
+                            * net_out = dpre [B][2R][T] = {dg*sg*(1-th^2), dg*th*sg*(1-sg)} with aux0 = th, aux1 = sg [B][R][T] */
+    const float* aux0;
+    const float* aux1;
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 

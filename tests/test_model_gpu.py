@@ -114,15 +114,15 @@ def test_default_width_short_segment(pkg):
     print('worst grad', worst)
 
 
-@pytest.mark.parametrize('mode', ['1', '2', '3', '4'])
+@pytest.mark.parametrize('mode', ['1', '2', '3', '4', '5'])
 def test_default_width_gate_f16x3(pkg, monkeypatch, mode):
     """The same parity run with the experimental fp16x3 gate convs switched on (VQW_GATE_F16X3=1):
     the oracle comparison holds at the SAME tolerances as the fp32-MFMA engine (VQ indices bit-exact, logits
     5e-4, losses 2e-5, gradients 5e-3 in relative L2)."""
-    monkeypatch.setenv('VQW_GATE_F16X3', mode)   # 1: gate convs, 2: + 1x1 skip/residual convs, 3: skip path as one contraction, 4: + the gate convs' input gradient
+    monkeypatch.setenv('VQW_GATE_F16X3', mode)   # 1: gate convs, 2: + 1x1 skip/residual convs, 3: skip path as one contraction, 4: + the gate convs' input gradient, 5: + gate backward
     m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
     probe = pkg.model.VQVAE(m, w, 109, device='cuda', seed=0)
-    assert probe.gate_f16x3 and probe.out_f16x3 == (mode in '234') and probe.skip_f16x3 == (mode in '34') and probe.dgrad_f16x3 == (mode == '4')
+    assert probe.gate_f16x3 and probe.out_f16x3 == (mode in '2345') and probe.skip_f16x3 == (mode in '345') and probe.dgrad_f16x3 == (mode in '45')
     del probe
     worst = run_parity(pkg, m, w, 109, 1, 1024, seed=3, steps=1, grad_tol=5e-3, err=l2err, check_params=False)
     print('worst grad', worst)

@@ -69,6 +69,8 @@ class F16x3OutDesc(C.Structure):
         ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('S', C.c_int32), ('w_scale_inv', C.c_float),
         ('Cin', C.c_int32), ('xp_kc0', C.c_int32), ('xp_KC', C.c_int32),
         ('ks', C.c_int32), ('dilation', C.c_int32), ('dir', C.c_int32),
+        ('planes_kc0', C.c_int32), ('planes_KC', C.c_int32), ('plane_scale', C.c_float), ('epi', C.c_int32),
+        ('aux0', _fp), ('aux1', _fp),
     ]
 
 _i, _f, _sz, _i64 = C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -109,7 +111,7 @@ SIGNATURES = {
     'vqw_ar_decode_run_async': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     'vqw_ar_decode_wait': (_i, [_fp]),
     'vqw_ar_decode_destroy': (_i, [_fp]),
-    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _fp]),
+    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _i, _fp]),
     'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),
     'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),

@@ -42,7 +42,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& p0, uint4& p1
 }
 
 // x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16
-__global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T, float scale) {
+__global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T, float scale, int kc0, int KC) {
     const size_t NB = (size_t)B * T;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NB * (C / 8)) return;
@@ -54,8 +54,8 @@ __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict_
     for (int e = 0; e < 8; ++e) v[e] = x[((size_t)b * C + kc * 8 + e) * T + t] * scale;
     uint4 p0, p1;
     split8(v, p0, p1);
-    planes[(size_t)kc * NB + row] = p0;
-    planes[((size_t)(C / 8) + kc) * NB + row] = p1;
+    planes[(size_t)(kc0 + kc) * NB + row] = p0;
+    planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
 }
 
 // w [ks][R][ldw] (kernel[k, Cin, Cout], filter columns 0..R-1, gate columns R..2R-1) -> planes [2][ks*R/8][2R][8],
@@ -206,13 +206,14 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
 
 // Four consecutive channels (rows 4 lhi .. 4 lhi + 3 of chunk kc) of one (batch, time) row as the lane's 8-byte
 // half of the 16-byte plane entries: the 64 lanes of a wave cover 32 rows x 16 bytes = 512 contiguous bytes per plane.
-__device__ __forceinline__ void store_plane_quad(void* planes, int KC, int NB, int kc, int row, int lhi, const float (&x)[4]) {
+__device__ __forceinline__ void store_plane_quad(void* planes, int KC, int NB, int kc, int row, int lhi, const float (&x)[4], float scale = 1.0f) {
     u16 h1[4], h2[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 a = (_Float16)x[e];
+        const float xs = x[e] * scale;
+        const _Float16 a = (_Float16)xs;
         h1[e] = f16_bits(a);
-        h2[e] = f16_bits((_Float16)(x[e] - (float)a));
+        h2[e] = f16_bits((_Float16)(xs - (float)a));
     }
     char* base = reinterpret_cast<char*>(planes) + ((size_t)kc * NB + row) * 16 + lhi * 8;
     *reinterpret_cast<uint2*>(base) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
@@ -340,7 +341,67 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
             if (!is_skip && d.net_out_planes) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    store_plane_quad(d.net_out_planes, R / 8, a.NB, (m0 - S) / 8, n0 + 64 * wv + 32 * j + l31, lhi, nq[j]);
+                    store_plane_quad(d.net_out_planes, d.planes_KC > 0 ? d.planes_KC : R / 8, a.NB, d.planes_kc0 + (m0 - S) / 8,
+                                     n0 + 64 * wv + 32 * j + l31, lhi, nq[j], d.plane_scale > 0.0f ? d.plane_scale : 1.0f);
+            }
+        }
+}
+
+// Gate backward (the transpose of gated_cnn's tanh * sigmoid, wavenet_ops.py:112-113, behind the transposed 1x1 convs):
+// dg = W_out^T [dskip; dnet] over the gradient planes (dskip in chunks 0..S/8-1, dnet behind it), then
+// dpre[filter c] = dg * sg * (1 - th^2), dpre[gate c] = dg * th * sg * (1 - sg); dpre also as planes for the input gradient.
+__global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const vqw_f16x3_out_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int R = d.R, T = d.T;
+    const int n_mt = R / 256;
+    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
+    const int b = n0 / T, t0 = n0 - b * T;
+    f32x16 acc[8][2];
+    {
+        LoopGeom g;
+        g.wp = d.wp; g.xp = d.xp; g.M = R; g.Cin = d.Cin; g.ks = 1; g.dilation = 1; g.NB = a.NB;
+        g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
+        g.xKC = d.xp_KC > 0 ? d.xp_KC : d.Cin / 8; g.xkc0 = d.xp_kc0; g.dir = 1; g.T = T;
+        f16x3_mainloop(acc, smem, g, wv, lane);
+    }
+    const int tcol = t0 + 64 * wv + l31;
+    const float ps = d.plane_scale > 0.0f ? d.plane_scale : 1.0f;
+    const int PKC = d.planes_KC > 0 ? d.planes_KC : 2 * R / 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            const int c0 = mt * 256 + 32 * i + 8 * v4 + 4 * lhi;     // first of this lane's four gated channels
+            const size_t offa = ((size_t)b * R + c0) * T + tcol;      // saved tanh / sigmoid [B][R][T]
+            const size_t offo = ((size_t)b * 2 * R + c0) * T + tcol;  // dpre [B][2R][T]: filter rows, then gate rows
+            const float* pt = d.aux0 + offa;
+            const float* pg = d.aux1 + offa;
+            float* pf = d.net_out + offo;
+            float* pq = pf + (size_t)R * T;
+            float th[2][4], sg[2][4], qf[2][4], qg[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { th[j][e] = pt[e * T + 32 * j]; sg[j][e] = pg[e * T + 32 * j]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float dg = acc[i][j][v4 * 4 + e] * d.w_scale_inv;
+                    qf[j][e] = dg * sg[j][e] * (1.0f - th[j][e] * th[j][e]);
+                    qg[j][e] = dg * th[j][e] * sg[j][e] * (1.0f - sg[j][e]);
+                    pf[e * T + 32 * j] = qf[j][e];
+                    pq[e * T + 32 * j] = qg[j][e];
+                }
+            if (d.net_out_planes) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    store_plane_quad(d.net_out_planes, PKC, a.NB, d.planes_kc0 + c0 / 8, n0 + 64 * wv + 32 * j + l31, lhi, qf[j], ps);
+                    store_plane_quad(d.net_out_planes, PKC, a.NB, d.planes_kc0 + (R + c0) / 8, n0 + 64 * wv + 32 * j + l31, lhi, qg[j], ps);
+                }
             }
         }
 }
@@ -349,12 +410,14 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
 
 extern "C" {
 
-int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, vqw_stream_t s_) {
+int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(x && planes, "vqw_f16x3_split_activations: null pointer");
     VQW_CHECK(B > 0 && T > 0 && C > 0 && C % 8 == 0, "vqw_f16x3_split_activations: C must be a positive multiple of 8 (got %d)", C);
+    if (KC <= 0) { KC = C / 8; kc0 = 0; }
+    VQW_CHECK(kc0 >= 0 && kc0 + C / 8 <= KC, "vqw_f16x3_split_activations: bad chunk range (kc0=%d KC=%d)", kc0, KC);
     const size_t n = (size_t)B * T * (C / 8);
-    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale);
+    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC);
     VQW_LAUNCH_CHECK("vqw_f16x3_split_activations");
     return 0;
 }
@@ -397,6 +460,14 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     a.NB = d.B * d.T;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(out_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
+    if (d.epi == 1) {   // gate backward
+        VQW_CHECK(d.S == 0 && d.R > 0 && d.aux0 && d.aux1 && d.Cin > 0, "vqw_f16x3_out_conv: gate backward needs S = 0, saved tanh (aux0) and sigmoid (aux1), Cin");
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gate_bwd_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+            return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
+        hipLaunchKernelGGL(gate_bwd_f16x3_kernel, dim3((d.R / 256) * (a.NB / 256)), dim3(256), NSTG * STG_BYTES, st, a);
+        VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");
+        return 0;
+    }
     const int blocks = ((d.S + d.R) / 256) * (a.NB / 256);
     hipLaunchKernelGGL(out_f16x3_kernel, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");

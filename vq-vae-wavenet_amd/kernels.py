@@ -201,11 +201,11 @@ def _need_planes(t, n_halves, what):
     L.require_cuda(t)
 
 
-def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0):
-    """scale * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16."""
+def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0):
+    """scale * x [B][C][T] fp32 -> planes [2][KC or C/8][B*T][8] fp16, chunks kc0..."""
     _need(x, B * Cc * T, 'x')
-    _need_planes(planes, 2 * B * Cc * T, 'planes')
-    L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, float(scale), L.stream()))
+    _need_planes(planes, 2 * B * T * (KC * 8 if KC else Cc), 'planes')
+    L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, float(scale), kc0, KC, L.stream()))
 
 
 def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1):
@@ -223,7 +223,8 @@ def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1):
 
 
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
-                   net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1):
+                   net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
+                   planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None):
     cin = Cin if Cin > 0 else R
     kc_all = xp_KC if xp_KC > 0 else cin // 8
     _need_planes(xp, 2 * kc_all * 8 * B * T, 'xp')
@@ -233,11 +234,14 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     if R:
         if net_in is not None:
             _need(net_in, B * R * T, 'net_in')
-        _need(net_out, B * R * T, 'net_out')
+        _need(net_out, B * R * T * (2 if epi == 1 else 1), 'net_out')
+    if epi == 1:
+        _need(aux0, B * R * T, 'aux0')
+        _need(aux1, B * R * T, 'aux1')
     if bias is not None:
         _need(bias, S + R, 'bias')
     if net_out_planes is not None:
-        _need_planes(net_out_planes, 2 * B * R * T, 'net_out_planes')
+        _need_planes(net_out_planes, 2 * B * T * (planes_KC * 8 if planes_KC else R * (2 if epi == 1 else 1)), 'net_out_planes')
     d = L.F16x3OutDesc()
     d.xp, d.wp = xp.data_ptr(), wp.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
@@ -248,6 +252,9 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     d.B, d.T, d.R, d.S = B, T, R, S
     d.Cin, d.xp_kc0, d.xp_KC = Cin, xp_kc0, xp_KC
     d.ks, d.dilation, d.dir = ks, dilation, direction
+    d.planes_kc0, d.planes_KC, d.plane_scale, d.epi = planes_kc0, planes_KC, float(plane_scale), epi
+    d.aux0 = None if aux0 is None else aux0.data_ptr()
+    d.aux1 = None if aux1 is None else aux1.data_ptr()
     d.w_scale_inv = float(w_scale_inv)
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 

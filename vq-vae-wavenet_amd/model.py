@@ -86,11 +86,13 @@ class VQVAE:
         # experimental: the decoder's gate convs on the fp16 matrix pipe with two-plane operands
         # '1': gate convs; '2': gate convs + the 1x1 skip/residual convs (which then hand over the next layer's planes)
         # '3': as '2', but the skip path of all layers as ONE contraction over the gated planes kept side by side
-        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2', '3', '4')
-        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('2', '3', '4')
+        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2', '3', '4', '5')
+        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('2', '3', '4', '5')
         # '4': as '3', and the gate convs' input gradient (backward) with the gradient operand lifted by 2^20
-        self.skip_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('3', '4')
-        self.dgrad_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '4'
+        self.skip_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('3', '4', '5')
+        # '5': as '4', and gate backward (dskip split once per step, dnet / dpre handed over as lifted planes)
+        self.dgrad_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('4', '5')
+        self.gbwd_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '5'
         self._side = None
         self._build_layout()
         self._init_params(seed)
@@ -307,6 +309,10 @@ class VQVAE:
             if self.dgrad_f16x3:
                 ws['dp'] = torch.empty(2 * B * 2 * R * T, dtype=torch.float16, device=dev)
                 ws['wdg'] = torch.empty(L, 2 * self.ks * 2 * R * R, dtype=torch.float16, device=dev)
+                if self.gbwd_f16x3:
+                    ws['gr'] = torch.empty(2 * B * (S + R) * T, dtype=torch.float16, device=dev)   # [dskip | dnet] lifted planes
+                    ws['wgb'] = torch.empty(L, 2 * (S + R) * R, dtype=torch.float16, device=dev)
+                    ws['wgb_top'] = torch.empty(2 * S * R, dtype=torch.float16, device=dev)
             if self.skip_f16x3:
                 ws['wskip'] = torch.empty(2 * L * R * S, dtype=torch.float16, device=dev)
                 ws['wres'] = torch.empty(L, 2 * R * R, dtype=torch.float16, device=dev)
@@ -534,8 +540,13 @@ class VQVAE:
         # gradient operand is lifted by 2^20 before it is split into fp16 planes (|dpre| < 0.06 assumed, not checked).
         dgrad_x3 = self.dgrad_f16x3 and T % 256 == 0 and R % 256 == 0
         GS = float(2 ** 20)
+        gbwd_x3 = dgrad_x3 and self.gbwd_f16x3 and S % 256 == 0
         if dgrad_x3:
             K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, 256.0, count=L)
+        if gbwd_x3:
+            K.f16x3_pack_weights(Tt['out_w'], ws['wgb'], S + R, R, R, 256.0, count=L)
+            K.f16x3_pack_weights(Tt['out_w'][L - 1], ws['wgb_top'], S, R, R, 256.0)       # the top layer has no dnet
+            K.f16x3_split_activations(dskip, ws['gr'], B, S, T, scale=GS, kc0=0, KC=(S + R) // 8)   # one tensor for all layers
         side_done = {}
         dnet = dnet_ring[(L - 1) % 3]
         for l in range(L - 1, -1, -1):
@@ -545,18 +556,26 @@ class VQVAE:
             dnet_next = dnet_ring[(l - 1) % 3]
             if side is not main and (l + 2) in side_done:
                 main.wait_event(side_done[l + 2])            # dpre[l % 2] and dnet[(l - 1) % 3] are free again
-            K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
-                        aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
-                        epilogue=K.EPI_GATE_BWD, tile=self.tiles['gate_bwd'])
+            if gbwd_x3:
+                K.f16x3_out_conv(epi=1, xp=ws['gr'], Cin=S if top else S + R, xp_KC=(S + R) // 8,
+                                 wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=ws['th'][l], aux1=ws['sg'][l], net_out=dpre,
+                                 net_out_planes=ws['dp'], plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (256.0 * GS))
+            else:
+                K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
+                            aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
+                            epilogue=K.EPI_GATE_BWD, tile=self.tiles['gate_bwd'])
             if side is not main:
                 ready = torch.cuda.Event()
                 ready.record(main)
             taps_b = [(ks - 1 - j) * d for j in range(ks)]
             if dgrad_x3:
-                K.f16x3_split_activations(dpre, ws['dp'], B, 2 * R, T, scale=GS)
+                if not gbwd_x3:      # (gate backward hands dpre over as planes)
+                    K.f16x3_split_activations(dpre, ws['dp'], B, 2 * R, T, scale=GS)
                 K.f16x3_out_conv(xp=ws['dp'], Cin=2 * R, ks=ks, dilation=d, direction=-1, wp=ws['wdg'][l],
                                  net_in=None if top else dnet, net_out=dnet_next, B=B, T=T, R=R, S=0,
-                                 w_scale_inv=1.0 / (256.0 * GS))
+                                 w_scale_inv=1.0 / (256.0 * GS),
+                                 net_out_planes=ws['gr'] if gbwd_x3 else None, planes_kc0=S // 8 if gbwd_x3 else 0,
+                                 planes_KC=(S + R) // 8 if gbwd_x3 else 0, plane_scale=GS if gbwd_x3 else 0.0)
             elif top:
                 K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
                             tile=self.tiles['dgrad'])
