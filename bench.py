@@ -249,26 +249,31 @@ def main():
     # Reported beside the headline, never as it: the same step with the opt-in fp16x3 forward convs
     exp = None
     if world == 1 and not a.no_experimental and os.environ.get('VQW_GATE_F16X3', '0') == '0':
-        os.environ['VQW_GATE_F16X3'] = '5'
         try:
-            model_x = pkg.model.VQVAE(m, w, S, device=dev, seed=0)
-        finally:
+            os.environ['VQW_GATE_F16X3'] = '5'
+            try:
+                model_x = pkg.model.VQVAE(m, w, S, device=dev, seed=0)
+            finally:
+                os.environ['VQW_GATE_F16X3'] = '0'
+            for _ in range(a.warmup):
+                model_x.train_step(x, spk)
+            torch.cuda.synchronize()
+            tx = time.perf_counter()
+            for _ in range(a.steps):
+                ws_x = model_x.train_step(x, spk)
+            torch.cuda.synchronize()
+            dtx = time.perf_counter() - tx
+            exp = {"switch": "VQW_GATE_F16X3=5", "what": "decoder forward gate / residual / skip convs as fp32-accurate 3-term contractions "
+                   "of two-plane fp16 operands on the fp16 matrix pipe (parity tests at the fp32 path's tolerances), and gate backward + the gate convs' input gradient likewise with the gradient operands lifted by 2^20; weight gradients and the encoder unchanged",
+                   "value": B * T * a.steps / dtx, "unit": "audio-samples/s", "ms_per_step": dtx / a.steps * 1e3,
+                   "loss": model_x.losses(ws_x)[0]}
+            log('experimental fp16x3 forward: %.2f ms/step, loss %.5f' % (exp["ms_per_step"], exp["loss"]))
+            del model_x, ws_x
+            torch.cuda.empty_cache()
+        except Exception as e:   # the headline must not depend on the opt-in path
             os.environ['VQW_GATE_F16X3'] = '0'
-        for _ in range(a.warmup):
-            model_x.train_step(x, spk)
-        torch.cuda.synchronize()
-        tx = time.perf_counter()
-        for _ in range(a.steps):
-            ws_x = model_x.train_step(x, spk)
-        torch.cuda.synchronize()
-        dtx = time.perf_counter() - tx
-        exp = {"switch": "VQW_GATE_F16X3=5", "what": "decoder forward gate / residual / skip convs as fp32-accurate 3-term contractions "
-               "of two-plane fp16 operands on the fp16 matrix pipe (parity tests at the fp32 path's tolerances), and gate backward + the gate convs' input gradient likewise with the gradient operands lifted by 2^20; weight gradients and the encoder unchanged",
-               "value": B * T * a.steps / dtx, "unit": "audio-samples/s", "ms_per_step": dtx / a.steps * 1e3,
-               "loss": model_x.losses(ws_x)[0]}
-        log('experimental fp16x3 forward: %.2f ms/step, loss %.5f' % (exp["ms_per_step"], exp["loss"]))
-        del model_x, ws_x
-        torch.cuda.empty_cache()
+            exp = {"switch": "VQW_GATE_F16X3=5", "error": '%s: %s' % (type(e).__name__, e)}
+            log('experimental fp16x3 leg failed: %s' % exp['error'])
 
     gen = None
     if not a.no_gen:
