@@ -1,5 +1,7 @@
-// EXPERIMENTAL (opt-in, VQW_GATE_F16X3=1 in model.py): the decoder's gate conv (wavenet_ops.py:104-114) as an
-// fp32-accurate contraction on the fp16 matrix pipe of gfx950.  DESIGN.md 3.2b has the arithmetic and its
+// EXPERIMENTAL (opt-in, VQW_GATE_F16X3=1..5 in model.py): the decoder layers' contractions -- the gate conv
+// (wavenet_ops.py:104-114), the 1x1 skip + residual conv (:132-136; the skip path of all layers also as one
+// contraction), gate backward and the gate conv's input gradient -- as fp32-accurate contractions on the fp16 matrix
+// pipe of gfx950.  DESIGN.md 3.2b has the arithmetic and its
 // measured error: every fp32 operand is split exactly enough into two fp16 pieces, x = h1 + h2,
 // h2 = fp16(x - h1), and  a*b ~ a1 b1 + a1 b2 + a2 b1  (every term exact in the fp32 accumulator of
 // v_mfma_f32_32x32x16_f16; the dropped a2 b2 is 2^-22 per product).  Same bytes per operand element as fp32,
@@ -11,8 +13,8 @@
 // dilation shift of a tap is a row offset (rows before the start of a batch row read as zero through the buffer
 // range check: the causal left padding of conv1d_v2, wavenet_ops.py:81).
 //
-// Block = 256 output channels (128 filter + the 128 matching gate channels, so tanh * sigmoid meets in one lane)
-// x 256 time steps; four waves, each all 256 channels x 64 time steps (16 accumulator tiles in AGPRs); K step = 16
+// Block = 256 output channels (gate conv: 128 filter + the 128 matching gate channels, so tanh * sigmoid meets in one
+// lane) x 256 time steps; four waves, each all 256 channels x 64 time steps (16 accumulator tiles in AGPRs); K step = 16
 // input channels of one tap; operands through VGPRs into a 4-stage LDS ring, MFMA fragments double-buffered in
 // registers (read from LDS one step ahead), one barrier per step.
 #include "vqw_common.h"
@@ -23,12 +25,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 __device__ __forceinline__ u16 f16_bits(_Float16 h) { return __builtin_bit_cast(u16, h); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_f(float x) {
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
-}
-
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& p0, uint4& p1) {
     u16 a[8], b[8];
 #pragma unroll
