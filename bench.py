@@ -173,6 +173,22 @@ def cpu_ar_baseline(steps):
             "sample": "%d greedy steps of the torch-CPU oracle generator, batch 1" % steps}
 
 
+def spawn_ranks(n):
+    """One process per GPU under torch.distributed.run (RCCL rendezvous on 127.0.0.1, a free port); returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('launching %d ranks: %s' % (n, ' '.join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -186,15 +202,36 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
     ap.add_argument('--no-experimental', action='store_true', help='skip the extra timing of the opt-in fp16x3 forward path')
+    ap.add_argument('--probe-ranks', action='store_true', help='only start the ranks and report how many joined (no GPU work)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 code path)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as FRESH child processes of
+        # torch.distributed.run, before this process has made any GPU call (it never makes one), and pass the one
+        # JSON line of rank 0 through.
+        raise SystemExit(spawn_ranks(a.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit('WORLD_SIZE=%d does not match --gpus %d' % (world, a.gpus))
-    local = local % max(torch.cuda.device_count(), 1)   # rehearsal: several ranks on one GPU
+    if a.probe_ranks:     # launcher check without a GPU: every rank joins a gloo group, rank 0 prints what the job looks like
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"probe": "ranks", "n_gpus": world, "ranks_seen": int(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    ndev = torch.cuda.device_count()
+    if world > max(ndev, 1) and a.backend == 'nccl':
+        raise SystemExit('--gpus %d needs %d GPUs, this node shows %d (RCCL cannot place two ranks on one GPU; '
+                         '--backend gloo rehearses the N>1 code path on fewer)' % (a.gpus, a.gpus, ndev))
+    local = local % max(ndev, 1)   # gloo rehearsal: several ranks on one GPU
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None

@@ -38,7 +38,7 @@ def main():
     pkg = importlib.import_module('vq-vae-wavenet_amd')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)   # no collective: ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -65,7 +65,14 @@ def main():
         spk_file, num_speakers = 'data/librispeech_speakers.txt', 251
     speaker_to_int = pkg.data.get_speaker_to_int(spk_file) if os.path.exists(spk_file) else {}
     # 'None' -> all-zero one-hot -> argmax 0 (generate.py:59-60, model.py:22)
-    ids = [0 if s.lower() == 'none' else speaker_to_int[s] for s in args.speakers]
+    ids = []
+    for sp in args.speakers:
+        if sp.lower() != 'none' and sp not in speaker_to_int:
+            raise ValueError('unknown speaker %r (not in %s)' % (sp, spk_file))
+        i = 0 if sp.lower() == 'none' else speaker_to_int[sp]
+        if not 0 <= i < num_speakers:
+            raise ValueError('speaker %r maps to %d, outside the %d-row speaker table' % (sp, i, num_speakers))
+        ids.append(i)
 
     parameters, wavenet_parameters = pkg.model.load_configs(args.parameter_path)
     model = pkg.model.VQVAE(parameters, wavenet_parameters, num_speakers, device=dev, seed=0)
@@ -79,16 +86,16 @@ def main():
     mine = list(range(rank, len(ids), world))  # shard speakers over GPUs: no collective needed
     if mine:
         B = len(mine)
-        x = torch.from_numpy(wav).to(dev).unsqueeze(0).repeat(B, 1).contiguous()
+        x = torch.from_numpy(wav).to(dev).unsqueeze(0).contiguous()       # ONE utterance: encoder + VQ run once,
         spk = torch.tensor([ids[i] for i in mine], dtype=torch.int64, device=dev)
-        enc = model.encode(x, spk)             # model.encoding, generate.py:92
+        enc = model.encode(x, spk)             # only the speaker rows differ (model.encoding, generate.py:40,92)
         out = np.zeros([B, length], dtype=np.float32)
         uniforms = None
-        if args.mode == 'sample':
+        if args.mode == 'sample':      # one row of uniforms per requested speaker, whatever the sharding
             g = torch.Generator().manual_seed(args.seed) if args.seed is not None else None
-            uniforms = torch.rand(B, length, generator=g).to(dev)
-        for b0 in range(0, B, 8):              # the AR decoder handles up to 8 rows at a time
-            rows = slice(b0, min(b0 + 8, B))
+            uniforms = torch.rand(len(ids), length, generator=g)[mine].contiguous().to(dev)
+        for b0 in range(0, B, 12):             # 12 rows = three 4-row handles in one persistent launch at R=256
+            rows = slice(b0, min(b0 + 12, B))
             gen = pkg.generator.FastGenerator(model, batch=rows.stop - rows.start)
             audio, _ = gen.generate(enc[rows].contiguous(), length, mode=args.mode, ratio=length // enc.shape[2],
                                     uniforms=None if uniforms is None else uniforms[rows].contiguous())

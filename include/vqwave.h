@@ -212,13 +212,15 @@ int vqw_vq_nearest_bwd(const float* z_e, const float* e_k, const int64_t* idx,
                        float cscale, float escale, int B, int D, int Tz, int K,
                        vqw_stream_t s);
 /* Speaker path, model.py:22-27 + decoder_ops.py:39-43:
- * cond[b*cond_bstride + (row0+j)*Tz + t] = table[spk[b]][j] for all t.                  */
+ * cond[b*cond_bstride + (row0+j)*Tz + t] = table[spk[b]][j] for all t.  table has n_speakers rows; an id
+ * outside [0, n_speakers) reads row 0 (the reference's one_hot -> argmax of an all-zero row, model.py:22),
+ * never memory outside the table.                                                        */
 int vqw_speaker_tile_fwd(const float* table, const int64_t* spk, float* cond,
-                         int64_t cond_bstride, int row0, int B, int Cs, int Tz,
+                         int64_t cond_bstride, int row0, int B, int Cs, int Tz, int n_speakers,
                          vqw_stream_t s);
 /* dtable[spk[b]][j] += sum_t dcond[b][row0+j][t] */
 int vqw_speaker_tile_bwd(const float* dcond, int64_t dcond_bstride, int row0,
-                         const int64_t* spk, float* dtable, int B, int Cs, int Tz,
+                         const int64_t* spk, float* dtable, int B, int Cs, int Tz, int n_speakers,
                          vqw_stream_t s);
 
 /* ------------------------------------------------------------------------------------
@@ -290,6 +292,18 @@ int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding, int Tz, in
                             int n_steps, int mode, const float* uniforms, float* audio,
                             int32_t* indices, float* probs_last, vqw_stream_t s);
 int vqw_ar_decode_wait(vqw_ar_decoder* h);
+/* Up to 4 handles (independent batch slices: rows never interact, generate.py:40,103-113) in ONE persistent launch,
+ * grid = (workgroups, n): they generate side by side whatever hardware queues the runtime maps streams to (two
+ * _run_async calls on two streams overlap only when those streams land on different queues).  Every handle must be on
+ * the persistent kernel with the same instantiation (vqw_ar_decode_workgroups > 0, equal batch class) and
+ * n * workgroups must not exceed the CU count (one resident workgroup per CU); per-handle pointer arrays, `uniforms`,
+ * `indices`, `probs_last` may be NULL as a whole.  Then vqw_ar_decode_wait on every handle.                      */
+int vqw_ar_decode_run_group_async(vqw_ar_decoder* const* hs, int n, const float* const* encoding, int Tz,
+                                  int ratio, int n_steps, int mode, const float* const* uniforms,
+                                  float* const* audio, int32_t* const* indices, float* const* probs_last,
+                                  vqw_stream_t s);
+/* workgroups (= CUs held for the whole run) of the handle's persistent kernel; 0: launch-per-phase path */
+int vqw_ar_decode_workgroups(const vqw_ar_decoder* h);
 int vqw_ar_decode_destroy(vqw_ar_decoder* h);
 
 /* ---- EXPERIMENTAL (opt-in; the fp32-MFMA engine above stays the default path): the decoder's gate conv

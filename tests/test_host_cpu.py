@@ -1,5 +1,6 @@
 """CPU tests of the host-side mirror: parameter inventory under the reference's variable names,
 LR schedule, data pipeline, CLI surface and the data-parallel gradient exchange (gloo, world 2)."""
+import json
 import os
 import subprocess
 import sys
@@ -146,3 +147,16 @@ def test_host_sampling_utils_match_oracle():
     np.testing.assert_array_equal(U.mu_law_decode_np(np.arange(257, dtype=np.float32)), R.mu_law_decode_np(np.arange(257, dtype=np.float32)))
     with pytest.raises(NotImplementedError):
         U.decode(pdf, mode='beam')
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two fresh ranks under torch.distributed.run (probe mode:
+    gloo group only, no GPU work anywhere); a WORLD_SIZE that contradicts --gpus is refused, never downgraded."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--probe-ranks'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert rec == {"probe": "ranks", "n_gpus": 2, "ranks_seen": 2}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--probe-ranks'],
+                         env=dict(os.environ, WORLD_SIZE='2', RANK='0'), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and 'does not match' in bad.stderr

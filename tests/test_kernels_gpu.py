@@ -1,8 +1,8 @@
 """GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle.
 
 Tolerances: integer / index outputs are compared bit-exactly; fp32 MFMA results against the
-torch-CPU fp32 oracle within rtol 2e-4 / atol 2e-4 scaled by the operand magnitude (both sides
-accumulate K<=2304 fp32 products in different orders).
+torch-CPU fp32 oracle within 2e-4 of the tensor max (`close`; both sides accumulate K<=2304 fp32
+products in different orders); weight gradients (53 248-term sums) 5e-4, 1e-3 at the full size.
 """
 import numpy as np
 import pytest
@@ -28,11 +28,15 @@ def btc(x_bct):
     return x_bct.detach().cpu().transpose(1, 2).contiguous()
 
 
-def close(a, b, rtol=2e-4, atol=2e-4, what=''):
+def close(a, b, rtol=None, atol=None, what=''):
+    """max |a - b| <= tol * max(1, max |b|), tol = the LARGER of rtol / atol where a test names them (they are one bar
+    relative to the tensor max, not two that add up), else the 2e-4 of the module docstring / DESIGN 6."""
+    given = [t for t in (rtol, atol) if t is not None]
+    tol = max(given) if given else 2e-4
     a, b = a.detach().cpu().float(), b.detach().cpu().float()
     scale = max(1.0, float(b.abs().max()))
     err = float((a - b).abs().max())
-    assert err <= atol * scale + rtol * scale, '%s max abs err %.3e (scale %.3e)' % (what, err, scale)
+    assert err <= tol * scale, '%s max abs err %.3e (scale %.3e)' % (what, err, scale)
 
 
 # ----------------------------------------------------------------------------- mu-law
@@ -42,6 +46,9 @@ def test_mu_law_int_all_pcm_codes_bit_exact(K):
     want = R.mu_law_encode_np(xs, to_int=True)
     got = K.mu_law_encode_i32(g(torch.from_numpy(xs))).cpu().numpy()
     assert np.array_equal(got, want)
+    import os
+    fixture = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mu_law_pcm_labels.npy'))   # committed vector
+    assert np.array_equal(got.astype(np.uint8), fixture)
 
 
 def test_mu_law_int_random_and_edges_bit_exact(K):
@@ -134,6 +141,16 @@ def test_vq_bwd_and_speaker(K):
     want = torch.zeros(S, Cs, device=DEV)
     want.index_add_(0, spk, dcond[:, D:].sum(-1))
     close(dt, want, what='dspeaker')
+    # ids outside the table: row 0, as the reference's one_hot -> argmax (model.py:22); never a read outside the table
+    bad = torch.tensor([S + 3, -1], dtype=torch.int64, device=DEV)
+    K.speaker_tile_fwd(table, bad, cond, cond_bstride=Cc * Tz, row0=D, Cs=Cs, Tz=Tz)
+    assert torch.equal(cond[:, D:], table[[0, 0]][:, :, None].expand(-1, -1, Tz))
+    dt.zero_()
+    K.speaker_tile_bwd(dcond, bad, dt, dcond_bstride=Cc * Tz, row0=D, Cs=Cs, Tz=Tz)
+    assert float(dt[1:].abs().max()) == 0.0
+    close(dt[0], dcond[:, D:].sum((0, 2)), what='out-of-range ids accumulate into row 0')
+    with pytest.raises(ValueError):
+        K.speaker_tile_fwd(table, spk.to(torch.int32), cond, cond_bstride=Cc * Tz, row0=D, Cs=Cs, Tz=Tz)
 
 
 # ----------------------------------------------------------------------------- conv engine

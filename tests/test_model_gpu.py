@@ -102,6 +102,33 @@ def test_tiny_model_matches_golden_fixture(pkg):
             assert relerr(got[key[5:]], torch.from_numpy(fx[key])) < 2e-3, key
         if key.startswith('new:'):
             assert relerr(newp[key[4:]], torch.from_numpy(fx[key])) < 1e-4, key
+    assert relerr(ws['z_e'].permute(0, 2, 1), torch.from_numpy(fx['z_e'])) < 2e-4
+    head = ws['logits'].permute(0, 2, 1).reshape(-1, model.Q)[:64]
+    assert relerr(head, torch.from_numpy(fx['logits_head'])) < 5e-4
+
+
+@pytest.mark.parametrize('persistent', ['1', '0'])
+def test_generation_matches_golden_fixture(pkg, monkeypatch, persistent):
+    """The committed 48 greedy steps of the oracle generator (tests/golden/tiny_model.npz: gen_idx, gen_audio;
+    generate.py:103-113 with the pre-step weights): the device generator reproduces the indices (a differing index is
+    accepted only where the oracle's decision is a near-tie, after which the comparison stops: the runs diverge)."""
+    monkeypatch.setenv('VQW_AR_PERSISTENT', persistent)
+    m, w = tiny_cfg()
+    fx = np.load(os.path.join(GOLD, 'tiny_model.npz'))
+    P = M.init_params(m, w, 10, seed=11, randomize_all=True)
+    model = build(pkg, m, w, 10, P)
+    x = torch.from_numpy(fx['x'])[:, :, 0].contiguous().cuda()
+    enc = model.encode(x, torch.from_numpy(fx['spk']).cuda())
+    n = fx['gen_idx'].shape[1]
+    gen = pkg.generator.FastGenerator(model, batch=2)
+    audio, idx = gen.generate(enc, n, ratio=n // enc.shape[2])           # generate.py:107: ratio = L // T_z
+    gen.close()
+    got, ga = idx.cpu().numpy(), audio.cpu().numpy()
+    for b in range(2):
+        same = got[b] == fx['gen_idx'][b]
+        upto = n if same.all() else int(np.argmin(same))
+        assert upto >= n - 8, 'row %d leaves the fixture at step %d' % (b, upto)   # tiny model: no near-ties seen
+        np.testing.assert_allclose(ga[b, :upto], fx['gen_audio'][b, :upto], rtol=1e-5, atol=1e-6)
 
 
 def test_default_width_short_segment(pkg):
@@ -146,10 +173,13 @@ def test_data_parallel_shards_sum_to_full_batch(pkg):
     assert relerr(avg, full.grad) < 2e-3
 
 
-def test_fast_generation_matches_oracle(pkg):
-    """vqw_ar_decode (ring buffers + on-device decode) vs the oracle's FIFO-queue generator
+@pytest.mark.parametrize('persistent', ['1', '0'])
+def test_fast_generation_matches_oracle(pkg, monkeypatch, persistent):
+    """Both generator back ends (persistent kernel; VQW_AR_PERSISTENT=0: the launch-per-phase path of ar_decode.hip).
+    vqw_ar_decode (ring buffers + on-device decode) vs the oracle's FIFO-queue generator
     (wavenet_ops.py:147-267, generate.py:103-113): greedy indices and sampling with supplied
     uniforms; a mismatch is only accepted where the oracle's own decision is a near-tie."""
+    monkeypatch.setenv('VQW_AR_PERSISTENT', persistent)
     m, w = tiny_cfg()
     P = M.init_params(m, w, 10, seed=11, randomize_all=True)
     model = build(pkg, m, w, 10, P)
@@ -249,6 +279,50 @@ def test_fast_generation_batch_split(pkg):
         a_s, i_s = small.generate(enc[r0:r0 + 2].contiguous(), 96, mode='sample', uniforms=u[r0:r0 + 2].contiguous())
         small.close()
         assert torch.equal(i_s, ib[r0:r0 + 2]) and torch.equal(a_s, ab[r0:r0 + 2])
+
+
+def test_fast_generation_more_rows_than_one_launch(pkg):
+    """20 rows = five 4-row handles; the chip holds only some of them at once (one resident workgroup per CU), so they
+    run as waves of co-resident handles (generator.CU_MARGIN) instead of half-resident grids spinning into their
+    timeout.  Every row equals the same row generated alone."""
+    m, w = tiny_cfg()
+    P = M.init_params(m, w, 10, seed=11, randomize_all=True)
+    model = build(pkg, m, w, 10, P)
+    x, spk, _ = M.synthetic_batch(20, 512, 10, 78)
+    enc = model.encode(x[:, :, 0].contiguous().cuda(), spk.cuda())
+    big = pkg.generator.FastGenerator(model, batch=20)
+    assert sum(big._parts) == 20 and len(big._parts) == 5 and sorted(i for wv in big._waves for i in wv) == list(range(5))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    nwg = pkg._lib.lib().vqw_ar_decode_workgroups(big._hs[0])
+    assert nwg > 0 and all(len(wv) * nwg <= cus for wv in big._waves)
+    ab, ib = big.generate(enc, 80)
+    big.close()
+    for r0 in (0, 6, 18):
+        small = pkg.generator.FastGenerator(model, batch=2)
+        a_s, i_s = small.generate(enc[r0:r0 + 2].contiguous(), 80)
+        small.close()
+        assert torch.equal(i_s, ib[r0:r0 + 2]) and torch.equal(a_s, ab[r0:r0 + 2])
+
+
+def test_encode_one_utterance_many_speakers_and_small_workspace(pkg):
+    """generate.py:40 repeats one utterance per speaker: encode() runs encoder + VQ once and tiles only the speaker rows;
+    its workspace is the encoder's, not the training step's (136 KB per audio sample)."""
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    model = pkg.model.VQVAE(m, w, 109, device='cuda', seed=0)
+    T = 16000 * 4                                                      # a 4 s clip
+    x, _, _ = M.synthetic_batch(1, T, 109, 5)
+    xd = x[:, :, 0].contiguous().cuda()
+    spk = torch.tensor([3, 17, 108, 0, 44, 45, 46, 47], dtype=torch.int64, device='cuda')
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    enc = model.encode(xd, spk)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 8 * 1024 * T, 'encode() of a %d-sample clip allocated %.1f MB' % (T, peak / 2 ** 20)   # < 8 KB per sample
+    rep = model.encode(xd.repeat(8, 1).contiguous(), spk)
+    assert torch.equal(enc, rep)
+    assert not any(k[2] for k in model._ws), 'encode() built a training workspace'
 
 
 def test_magenta_encoder_model_parity(pkg):

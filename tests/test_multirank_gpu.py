@@ -1,0 +1,99 @@
+"""N > 1 on the GPU box (ONE GPU there): fresh child ranks over gloo.
+
+* two data-parallel ranks, half the batch each, through model.train_step with parallel.GradAllReduce: the summed
+  gradient / world equals the single-rank full-batch gradient, both ranks end with bit-identical parameters, and those
+  equal the full-batch step's (what RCCL all-reduce + 1/world does on a node).
+* generate.py with WORLD_SIZE=2: speakers are sharded over the ranks with no collective (generate.py:40,103-113 rows
+  never interact) and every rank's WAVs equal the single-process run's bit for bit.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(argv, world, extra_env=None, cwd=None):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=cwd, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    return outs
+
+
+def test_two_ranks_average_to_full_batch_step(pkg, tmp_path):
+    run_ranks([os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path), 'gloo'], 2)
+    r0 = torch.load(str(tmp_path / 'rank0.pt'), weights_only=True)
+    r1 = torch.load(str(tmp_path / 'rank1.pt'), weights_only=True)
+    assert torch.equal(r0['grad_sum'], r1['grad_sum']), 'ranks hold different reduced gradients'
+    assert torch.equal(r0['flat'], r1['flat']) and torch.equal(r0['ema'], r1['ema']), 'ranks diverged after the step'
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_worker
+    m, w, P, x, spk = dp_worker.shared_problem()
+    full = pkg.model.VQVAE(m, w, 10, device='cuda', seed=0)
+    full.load_named(P)
+    full.train_step(x.cuda(), spk.cuda())
+    g_full, g_avg = full.grad.cpu(), r0['grad_sum'] / 2
+    assert float((g_avg - g_full).abs().max()) < 1e-4 * float(g_full.abs().max()), 'sum / world != full-batch gradient'
+    # Adam normalises by sqrt(v): compare the stepped parameters where the gradient is not at rounding level
+    big = g_full.abs() > 1e-3 * g_full.abs().max()
+    assert float((r0['flat'] - full.flat.cpu())[big].abs().max()) < 1e-5
+    assert not torch.equal(r0['grad_sum'], g_full)        # it really was a sum of two different shards
+
+
+def _tiny_checkpoint(tmp_path):
+    w = {"verbose": False, "quantization_channels": 256, "num_cycles": 1, "num_cycle_layers": 4,
+         "dilation_rates": [1, 2, 4, 8], "kernel_size": 3, "dilation_filters": 32, "skip_filters": 64,
+         "residual_filters": 32, "preprocess": {"kernel_size": 32, "filters": 32}}
+    m = {"encoder": "64", "use_vq": True, "speaker_embedding": 16, "k": 32, "latent_dim": 16, "beta": 0.25,
+         "encoder_filters": 48, "wavenet_parameters": str(tmp_path / 'w.json'), "verbose": False,
+         "learning_rate_schedule": {"0": 1e-3}}
+    (tmp_path / 'w.json').write_text(json.dumps(w))
+    (tmp_path / 'm.json').write_text(json.dumps(m))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '-dataset', 'synthetic', '-length', '512',
+                          '-batch', '2', '-step', '2', '-interval', '2', '-save', 'saved_model/weights', '-params',
+                          str(tmp_path / 'm.json')], cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=ROOT),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return tmp_path / 'saved_model' / 'weights-2.pt'
+
+
+def test_generate_shards_speakers_over_ranks(tmp_path):
+    from scipy.io import wavfile
+    ckpt = _tiny_checkpoint(tmp_path)
+    (tmp_path / 'data').mkdir()
+    (tmp_path / 'data' / 'vctk_speakers.txt').write_text('p225, 3\np226, 5\np227, 7\n')
+    t = np.arange(1100) / 16000.0
+    wavfile.write(str(tmp_path / 'a.wav'), 16000, (np.sin(2 * np.pi * 220 * t) * 8000).astype(np.int16))
+    argv = [os.path.join(ROOT, 'generate.py'), '-restore', str(ckpt), '-audio', str(tmp_path / 'a.wav'), '-speakers',
+            'p225', 'p226', 'p227', '-mode', 'sample', '-seed', '3', '-params', str(tmp_path / 'm.json')]
+    run_ranks(argv, 1, cwd=str(tmp_path))
+    names = ['2_p225.wav', '2_p226.wav', '2_p227.wav']
+    single = [wavfile.read(str(tmp_path / 'saved_model' / n))[1] for n in names]
+    for n in names:
+        os.remove(str(tmp_path / 'saved_model' / n))
+    outs = run_ranks(argv, 2, cwd=str(tmp_path))
+    assert '2_p225.wav' in outs[0][0] and '2_p227.wav' in outs[0][0] and '2_p226.wav' in outs[1][0]   # rank 0: rows 0, 2
+    for n, want in zip(names, single):
+        got = wavfile.read(str(tmp_path / 'saved_model' / n))[1]
+        assert np.array_equal(got, want), n

@@ -101,8 +101,8 @@ SIGNATURES = {
     'vqw_transpose': (_i, [_fp, _fp, _i, _i, _i, _fp]),
     'vqw_vq_nearest_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _i64, _fp, _i, _i, _i, _i, _fp]),
     'vqw_vq_nearest_bwd': (_i, [_fp, _fp, _fp, _fp, _i64, _fp, _fp, _f, _f, _i, _i, _i, _i, _fp]),
-    'vqw_speaker_tile_fwd': (_i, [_fp, _fp, _fp, _i64, _i, _i, _i, _i, _fp]),
-    'vqw_speaker_tile_bwd': (_i, [_fp, _i64, _i, _fp, _fp, _i, _i, _i, _fp]),
+    'vqw_speaker_tile_fwd': (_i, [_fp, _fp, _fp, _i64, _i, _i, _i, _i, _i, _fp]),
+    'vqw_speaker_tile_bwd': (_i, [_fp, _i64, _i, _fp, _fp, _i, _i, _i, _i, _fp]),
     'vqw_softmax_xent': (_i, [_fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _fp]),
     'vqw_adam_ema_step': (_i, [_fp, _fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _f, _fp]),
     'vqw_ar_decode_create': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i]),
@@ -110,6 +110,9 @@ SIGNATURES = {
     'vqw_ar_decode_run': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     'vqw_ar_decode_run_async': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     'vqw_ar_decode_wait': (_i, [_fp]),
+    'vqw_ar_decode_run_group_async': (_i, [C.POINTER(_fp), _i, C.POINTER(_fp), _i, _i, _i, _i, C.POINTER(_fp), C.POINTER(_fp),
+                                           C.POINTER(_fp), C.POINTER(_fp), _fp]),
+    'vqw_ar_decode_workgroups': (_i, [_fp]),
     'vqw_ar_decode_destroy': (_i, [_fp]),
     'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _i, _fp]),
     'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),

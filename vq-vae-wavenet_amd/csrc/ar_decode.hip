@@ -327,6 +327,7 @@ struct vqw_ar_decoder {
     bool use_graph = true;
     ArPersist* persist = nullptr;  // persistent single-launch generator (default model shapes)
     bool pending = false;          // a run has been enqueued and not yet waited for
+    hipStream_t run_stream = nullptr;   // the stream that run was enqueued on (a group run: the first handle's)
 };
 
 namespace {
@@ -479,12 +480,13 @@ extern "C" int vqw_ar_decode_wait(vqw_ar_decoder* h) {
     VQW_CHECK(h, "vqw_ar_decode_wait: null handle");
     if (!h->pending) return 0;
     h->pending = false;
+    hipStream_t st = h->run_stream ? h->run_stream : h->stream;
     if (h->persist) {
-        const int rc = arp_error(h->persist, h->stream);
+        const int rc = arp_error(h->persist, st);
         if (rc) return vqw_set_error("vqw_ar_decode_run: persistent kernel %s", rc > 0 ? "timed out waiting for a workgroup" : "failed");
         return 0;
     }
-    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -496,26 +498,19 @@ extern "C" int vqw_ar_decode_run(vqw_ar_decoder* h, const float* encoding, int T
     return vqw_ar_decode_wait(h);
 }
 
-extern "C" int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding, int Tz, int ratio, int n_steps,
-                                       int mode, const float* uniforms, float* audio, int32_t* indices,
-                                       float* probs_last, vqw_stream_t s) {
-    VQW_CHECK(h && encoding, "vqw_ar_decode_run: null pointer");
-    if (h->pending) {
-        const int rcw = vqw_ar_decode_wait(h);
-        if (rcw) return rcw;
-    }
-    VQW_CHECK(Tz > 0 && ratio > 0 && n_steps > 0, "vqw_ar_decode_run: bad Tz/ratio/n_steps");
-    VQW_CHECK(mode == 0 || (mode == 1 && uniforms), "vqw_ar_decode_run: mode must be 0 (greedy) or 1 (sample, needs uniforms)");
+extern "C" int vqw_ar_decode_workgroups(const vqw_ar_decoder* h) {
+    return (h && h->persist) ? arp_workgroups(h->persist) : 0;
+}
+
+namespace {
+
+// (re)allocate + compute the per-frame condition projections of one handle for this utterance, on `st`
+int project_condition(vqw_ar_decoder* h, const float* encoding, int Tz, hipStream_t st) {
     const vqw_ar_weights& w = h->w;
     const int L = w.n_layers, B = h->B;
-    hipStream_t user = (hipStream_t)s;
-    hipStream_t st = h->stream;
-    HIPC(hipEventRecord(h->ev_in, user));
-    HIPC(hipStreamWaitEvent(st, h->ev_in, 0));
-
-    // (re)allocate + compute the per-frame condition projections for this utterance
     if (Tz > h->cond_Tz_cap) {
         HIPC(hipStreamSynchronize(st));
+        if (h->run_stream && h->run_stream != st) HIPC(hipStreamSynchronize(h->run_stream));
         for (int l = 0; l <= L; ++l) {
             if (h->condenc[l]) (void)hipFree(h->condenc[l]);
             const size_t n = (size_t)B * (l < L ? 2 * w.R : w.S) * Tz;
@@ -536,11 +531,32 @@ extern "C" int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding,
         const int rc = vqw_conv_gemm(&d, st);
         if (rc) return rc;
     }
-    if (h->persist) {   // one launch for the whole run; waits for completion to report a spin-wait timeout
-        const int rc = arp_run(h->persist, h->condenc.data(), Tz, ratio, n_steps, mode, uniforms, audio, indices, probs_last, st);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding, int Tz, int ratio, int n_steps,
+                                       int mode, const float* uniforms, float* audio, int32_t* indices,
+                                       float* probs_last, vqw_stream_t s) {
+    if (h && h->persist)
+        return vqw_ar_decode_run_group_async(&h, 1, &encoding, Tz, ratio, n_steps, mode, uniforms ? &uniforms : nullptr, &audio,
+                                             indices ? &indices : nullptr, probs_last ? &probs_last : nullptr, s);
+    VQW_CHECK(h && encoding, "vqw_ar_decode_run: null pointer");
+    if (h->pending) {
+        const int rcw = vqw_ar_decode_wait(h);
+        if (rcw) return rcw;
+    }
+    VQW_CHECK(Tz > 0 && ratio > 0 && n_steps > 0, "vqw_ar_decode_run: bad Tz/ratio/n_steps");
+    VQW_CHECK(mode == 0 || (mode == 1 && uniforms), "vqw_ar_decode_run: mode must be 0 (greedy) or 1 (sample, needs uniforms)");
+    hipStream_t user = (hipStream_t)s;
+    hipStream_t st = h->stream;
+    h->run_stream = st;
+    HIPC(hipEventRecord(h->ev_in, user));
+    HIPC(hipStreamWaitEvent(st, h->ev_in, 0));
+    {
+        const int rc = project_condition(h, encoding, Tz, st);
         if (rc) return rc;
-        h->pending = true;   // the caller's stream is NOT made to wait: that would serialise handles started back to back
-        return 0;
     }
     // run parameters -> device state (step / run_base live on the device)
     ArState hs;
@@ -575,8 +591,48 @@ extern "C" int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding,
     return 0;
 }
 
+extern "C" int vqw_ar_decode_run_group_async(vqw_ar_decoder* const* hs, int n, const float* const* encoding, int Tz,
+                                             int ratio, int n_steps, int mode, const float* const* uniforms,
+                                             float* const* audio, int32_t* const* indices,
+                                             float* const* probs_last, vqw_stream_t s) {
+    VQW_CHECK(hs && encoding && audio && n >= 1 && n <= 4, "vqw_ar_decode_run_group: null pointer or n=%d outside 1..4", n);
+    VQW_CHECK(Tz > 0 && ratio > 0 && n_steps > 0, "vqw_ar_decode_run: bad Tz/ratio/n_steps");
+    VQW_CHECK(mode == 0 || (mode == 1 && uniforms), "vqw_ar_decode_run: mode must be 0 (greedy) or 1 (sample, needs uniforms)");
+    for (int i = 0; i < n; ++i) {
+        VQW_CHECK(hs[i] && encoding[i] && audio[i] && (mode == 0 || uniforms[i]), "vqw_ar_decode_run_group: null pointer (handle %d)", i);
+        VQW_CHECK(hs[i]->persist && arp_same_launch(hs[0]->persist, hs[i]->persist),
+                  "vqw_ar_decode_run_group: every handle must run the same persistent kernel (start the others one by one)");
+        for (int j = 0; j < i; ++j) VQW_CHECK(hs[j] != hs[i], "vqw_ar_decode_run_group: handle %d given twice", i);
+        if (hs[i]->pending) {
+            const int rcw = vqw_ar_decode_wait(hs[i]);
+            if (rcw) return rcw;
+        }
+    }
+    // everything is enqueued on the FIRST handle's stream, ordered after the work already in `s`; the caller's stream is
+    // not made to wait (vqw_ar_decode_wait blocks the host instead and reports spin-wait timeouts)
+    hipStream_t st = hs[0]->stream;
+    HIPC(hipEventRecord(hs[0]->ev_in, (hipStream_t)s));
+    HIPC(hipStreamWaitEvent(st, hs[0]->ev_in, 0));
+    ArPersist* ps[4];
+    const float* const* conds[4];
+    for (int i = 0; i < n; ++i) {
+        const int rc = project_condition(hs[i], encoding[i], Tz, st);
+        if (rc) return rc;
+        ps[i] = hs[i]->persist;
+        conds[i] = hs[i]->condenc.data();
+    }
+    const int rc = arp_run(ps, n, conds, Tz, ratio, n_steps, mode, uniforms, audio, indices, probs_last, st);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        hs[i]->pending = true;
+        hs[i]->run_stream = st;
+    }
+    return 0;
+}
+
 extern "C" int vqw_ar_decode_destroy(vqw_ar_decoder* h) {
     if (!h) return 0;
+    if (h->pending) (void)vqw_ar_decode_wait(h);   // a group run lives on another handle's stream
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_all(h);
     return 0;

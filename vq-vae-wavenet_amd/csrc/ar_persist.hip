@@ -79,6 +79,15 @@ struct PArgs {
 #endif
 };
 
+// One launch may carry up to PGROUP handles (independent batch slices generating side by side): grid = (nwg, n_handles),
+// workgroup (x, y) works on handle y.  ONE launch, because two persistent kernels on two streams only overlap when the
+// runtime happens to map the streams to different hardware queues (it did not in bench.py once a third stream existed:
+// 255 instead of 134 us per step for 8 utterances).
+constexpr int PGROUP = 4;
+struct PGroup {
+    PArgs h[PGROUP];
+};
+
 // LDS carve (in floats), shared by the host (size) and the device (offsets)
 struct Carve {
     int xfresh, xpast, hx1, hx2, hw, bias, condc, xh, misc, tab, dtab, total;
@@ -317,7 +326,8 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
 // (Compile-time load counts let the compiler wait with exact vmcnt values: with a run-time count it falls back to
 // vmcnt(0) in front of the first use, i.e. waits for the loads it has requested a moment earlier.)
 template <int TB, int RLT, int NS, int KS, int CPB>
-__global__ __launch_bounds__(NTHR, 1) void ar_persist_kernel(const PArgs a) {
+__global__ __launch_bounds__(NTHR, 1) void ar_persist_kernel(const PGroup grp) {
+    const PArgs& a = grp.h[blockIdx.y];
     extern __shared__ float lds[];
     constexpr int LPC = NCT / CPB;                        // lanes per channel
     constexpr int PUBL = LPC - 1;                         // the lane that ends up with a channel's sums and publishes them
@@ -987,20 +997,40 @@ int arp_reset(ArPersist* h, hipStream_t st) {
     return 0;
 }
 
-int arp_run(ArPersist* h, const float* const* condenc, int Tz, int ratio, int n_steps, int mode, const float* uniforms,
-            float* audio, int32_t* indices, float* probs_last, hipStream_t st) {
-    const int L = h->w.n_layers;
-    PHIPC(hipMemcpyAsync(h->dcond, condenc, (L + 1) * sizeof(float*), hipMemcpyHostToDevice, st));
-    PArgs a = h->args;
-    a.Tz = Tz; a.ratio = ratio; a.mode = mode; a.n_steps = n_steps;
-    a.uniforms = uniforms; a.audio = audio; a.indices = indices; a.probs_last = probs_last;
+int arp_workgroups(const ArPersist* h) { return h->nwg; }
+
+bool arp_same_launch(const ArPersist* x, const ArPersist* y) {
+    return x->kfn == y->kfn && x->nwg == y->nwg && x->lds_bytes == y->lds_bytes;
+}
+
+int arp_run(ArPersist* const* hs, int n, const float* const* const* condenc, int Tz, int ratio, int n_steps, int mode,
+            const float* const* uniforms, float* const* audio, int32_t* const* indices, float* const* probs_last,
+            hipStream_t st) {
+    if (n < 1 || n > PGROUP) return vqw_set_error("vqw_ar_decode_run: 1..%d handles per launch (got %d)", PGROUP, n);
+    const int cus = device_cus();
+    if (n * hs[0]->nwg > cus)
+        return vqw_set_error("vqw_ar_decode_run: %d handles x %d workgroups do not fit %d CUs (one resident workgroup per CU)",
+                             n, hs[0]->nwg, cus);
+    PGroup g;
+    memset(&g, 0, sizeof(g));
+    for (int i = 0; i < n; ++i) {
+        ArPersist* h = hs[i];
+        if (!arp_same_launch(hs[0], h)) return vqw_set_error("vqw_ar_decode_run: handles of one launch must share one kernel");
+        const int L = h->w.n_layers;
+        PHIPC(hipMemcpyAsync(h->dcond, condenc[i], (L + 1) * sizeof(float*), hipMemcpyHostToDevice, st));
+        PArgs a = h->args;
+        a.Tz = Tz; a.ratio = ratio; a.mode = mode; a.n_steps = n_steps;
+        a.uniforms = uniforms ? uniforms[i] : nullptr; a.audio = audio[i];
+        a.indices = indices ? indices[i] : nullptr; a.probs_last = probs_last ? probs_last[i] : nullptr;
 #ifdef VQW_AR_TRACE
-    if (!h->trace) h->trace = (u64*)pmalloc(h, (size_t)h->nwg * 16 * 16 * sizeof(u64));
-    a.trace = h->trace;
-    h->trace_steps = n_steps;
+        if (!h->trace) h->trace = (u64*)pmalloc(h, (size_t)h->nwg * 16 * 16 * sizeof(u64));
+        a.trace = h->trace;
+        h->trace_steps = n_steps;
 #endif
-    void* params[] = {&a};
-    PHIPC(hipLaunchKernel(h->kfn, dim3(h->nwg), dim3(NTHR), params, h->lds_bytes, st));
+        g.h[i] = a;
+    }
+    void* params[] = {&g};
+    PHIPC(hipLaunchKernel(hs[0]->kfn, dim3(hs[0]->nwg, n), dim3(NTHR), params, hs[0]->lds_bytes, st));
     return 0;
 }
 

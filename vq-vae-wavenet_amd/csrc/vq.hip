@@ -109,26 +109,31 @@ __global__ __launch_bounds__(256) void vq_nearest_bwd_lds_kernel(const float* __
 
 __global__ void speaker_tile_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ spk,
                                         float* __restrict__ cond, long cond_bstride, int row0, int B,
-                                        int Cs, int Tz) {
+                                        int Cs, int Tz, int n_speakers) {
     const size_t n = (size_t)B * Cs * Tz;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int t = (int)(i % Tz);
         const int j = (int)((i / Tz) % Cs);
         const int b = (int)(i / ((size_t)Tz * Cs));
-        cond[(size_t)b * cond_bstride + (size_t)(row0 + j) * Tz + t] = table[(size_t)spk[b] * Cs + j];
+        // model.py:22: one_hot -> argmax; an id outside the table is an all-zero one-hot row, whose argmax is 0
+        const int64_t id = spk[b];
+        const size_t row = (id >= 0 && id < n_speakers) ? (size_t)id : 0;
+        cond[(size_t)b * cond_bstride + (size_t)(row0 + j) * Tz + t] = table[row * Cs + j];
     }
 }
 
 __global__ void speaker_tile_bwd_kernel(const float* __restrict__ dcond, long dcond_bstride, int row0,
                                         const int64_t* __restrict__ spk, float* __restrict__ dtable,
-                                        int B, int Cs, int Tz) {
+                                        int B, int Cs, int Tz, int n_speakers) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * Cs) return;
     const int b = i / Cs, j = i % Cs;
     const float* r = dcond + (size_t)b * dcond_bstride + (size_t)(row0 + j) * Tz;
     float s = 0.0f;
     for (int t = 0; t < Tz; ++t) s += r[t];
-    unsafeAtomicAdd(dtable + (size_t)spk[b] * Cs + j, s);
+    const int64_t id = spk[b];
+    const size_t row = (id >= 0 && id < n_speakers) ? (size_t)id : 0;     // same row the forward pass read
+    unsafeAtomicAdd(dtable + row * Cs + j, s);
 }
 
 }  // namespace
@@ -177,22 +182,22 @@ extern "C" int vqw_vq_nearest_bwd(const float* z_e, const float* e_k, const int6
 }
 
 extern "C" int vqw_speaker_tile_fwd(const float* table, const int64_t* spk, float* cond, int64_t cond_bstride,
-                                    int row0, int B, int Cs, int Tz, vqw_stream_t s) {
-    VQW_CHECK(table && spk && cond && B > 0 && Cs > 0 && Tz > 0, "vqw_speaker_tile_fwd: bad arguments");
+                                    int row0, int B, int Cs, int Tz, int n_speakers, vqw_stream_t s) {
+    VQW_CHECK(table && spk && cond && B > 0 && Cs > 0 && Tz > 0 && n_speakers > 0, "vqw_speaker_tile_fwd: bad arguments");
     const size_t n = (size_t)B * Cs * Tz;
     int g = (int)((n + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(speaker_tile_fwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)s, table, spk, cond,
-                       (long)cond_bstride, row0, B, Cs, Tz);
+                       (long)cond_bstride, row0, B, Cs, Tz, n_speakers);
     VQW_LAUNCH_CHECK("vqw_speaker_tile_fwd");
     return 0;
 }
 
 extern "C" int vqw_speaker_tile_bwd(const float* dcond, int64_t dcond_bstride, int row0, const int64_t* spk,
-                                    float* dtable, int B, int Cs, int Tz, vqw_stream_t s) {
-    VQW_CHECK(dcond && spk && dtable && B > 0 && Cs > 0 && Tz > 0, "vqw_speaker_tile_bwd: bad arguments");
+                                    float* dtable, int B, int Cs, int Tz, int n_speakers, vqw_stream_t s) {
+    VQW_CHECK(dcond && spk && dtable && B > 0 && Cs > 0 && Tz > 0 && n_speakers > 0, "vqw_speaker_tile_bwd: bad arguments");
     hipLaunchKernelGGL(speaker_tile_bwd_kernel, dim3(vqw_cdiv(B * Cs, 256)), dim3(256), 0, (hipStream_t)s,
-                       dcond, (long)dcond_bstride, row0, spk, dtable, B, Cs, Tz);
+                       dcond, (long)dcond_bstride, row0, spk, dtable, B, Cs, Tz, n_speakers);
     VQW_LAUNCH_CHECK("vqw_speaker_tile_bwd");
     return 0;
 }

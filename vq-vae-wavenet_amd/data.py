@@ -59,6 +59,9 @@ class WavDataset:
             self.files = [ln.strip() for ln in f if ln.strip()]
         self.speaker_to_int = get_speaker_to_int(os.path.join(relative_path, speakers_name))
         self.num_speakers = len(self.speaker_to_int)
+        bad = {k: v for k, v in self.speaker_to_int.items() if not 0 <= v < self.num_speakers}
+        if bad:      # the id indexes the [num_speakers][Cs] embedding table (model.py:19-27)
+            raise ValueError('%s: speaker ids outside 0..%d: %s' % (speakers_name, self.num_speakers - 1, sorted(bad.items())[:5]))
         self.rng = np.random.RandomState(seed + 7919 * rank)
 
     def _read(self, rel):

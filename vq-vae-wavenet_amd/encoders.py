@@ -83,7 +83,7 @@ class EncoderMagenta:
         K.transpose(P['mag_r_w'], Tt['mag_r_w'], L, F, F)
         K.transpose(P['mag_post_w'], Tt['mag_post_w'], 1, F, D)
 
-    def workspace(self, ws, B, T, dev):
+    def workspace(self, ws, B, T, dev, train=True):
         F, L = self.FILTERS, len(self.DIL)
         e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
         Tl = [T // (2 ** (i + 1)) for i in range(L)]
@@ -91,6 +91,9 @@ class EncoderMagenta:
         ws['m_en'] = [e(B, F, T)] + [e(B, F, t) for t in Tl]     # en_0 .. en_6
         ws['m_dd'] = [e(B, F, t) for t in Tl]
         ws['m_gated'] = [e(B, F, t) for t in Tl]
+        if not train:       # forward only (model.encode): nothing is saved for a backward pass
+            ws['m_th'] = ws['m_sg'] = [None] * L
+            return
         ws['m_th'] = [e(B, F, t) for t in Tl]
         ws['m_sg'] = [e(B, F, t) for t in Tl]
         ws['m_den'] = [e(B, F, T)] + [e(B, F, t) for t in Tl]    # gradients w.r.t. en_i
@@ -236,7 +239,7 @@ class Encoder2019:
             raise ValueError('length must be a multiple of 320 for Encoder_2019 (got %d)' % T)
         return T // 320
 
-    def workspace(self, ws, B, T, dev):
+    def workspace(self, ws, B, T, dev, train=True):
         F = self.F
         e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
         Fr = T // 160
@@ -246,6 +249,9 @@ class Encoder2019:
         Ts = [Fr, Fr] + [Tz] * 7
         ws['e_T'] = Ts
         ws['e_a'] = [e(B, F, t) for t in Ts]          # layer outputs a_0 .. a_8
+        if not train:       # forward only (model.encode)
+            ws['e_r'] = [None] * len(Ts)
+            return
         ws['e_r'] = [e(B, F, t) for t in Ts]          # relu outputs before residual / doubling
         ws['e_da'] = [e(B, F, t) for t in Ts]         # gradients w.r.t. a_i
         ws['e_dc'] = [e(B, F, Fr), e(B, F, Tz)]       # masked conv-output gradients (per resolution)
@@ -258,16 +264,16 @@ class Encoder2019:
         k3 = [-1, 0, 1]                                                            # 'same', k=3: pads (1,1)
         K.conv_gemm(x0=ws['e_mf'], w=P['e19_w0'], bias=P['e19_b'][0], out0=a[0], B=B, T_in=Fr, T_out=Fr, M=F,
                     C0=self.CPAD, taps=k3, out_relu=True)
-        K.conv_gemm(x0=a[0], w=P['e19_wk3'][0], bias=P['e19_b'][1], out0=a[1], save0=r[1], aux1=a[0], B=B, T_in=Fr,
+        K.conv_gemm(x0=a[0], w=P['e19_wk3'][0], bias=P['e19_b'][1], out0=a[1], save0=r[1] if save else None, aux1=a[0], B=B, T_in=Fr,
                     T_out=Fr, M=F, C0=F, taps=k3, out_relu=True)
         pl, _ = same_pads(Fr, 4, 2)
         K.conv_gemm(x0=a[1], w=P['e19_w2'], bias=P['e19_b'][2], out0=a[2], B=B, T_in=Fr, T_out=Tz, M=F, C0=F,
                     in_stride=2, taps=[j - pl for j in range(4)], out_relu=True)
         for i in (3, 4):
-            K.conv_gemm(x0=a[i - 1], w=P['e19_wk3'][self.K3[i]], bias=P['e19_b'][i], out0=a[i], save0=r[i],
+            K.conv_gemm(x0=a[i - 1], w=P['e19_wk3'][self.K3[i]], bias=P['e19_b'][i], out0=a[i], save0=r[i] if save else None,
                         aux1=a[i - 1], B=B, T_in=Tz, T_out=Tz, M=F, C0=F, taps=k3, out_relu=True)
         for i in (5, 6, 7, 8):                                                     # net = relu + relu
-            K.conv_gemm(x0=a[i - 1], w=P['e19_wk3'][self.K3[i]], bias=P['e19_b'][i], out0=a[i], save0=r[i],
+            K.conv_gemm(x0=a[i - 1], w=P['e19_wk3'][self.K3[i]], bias=P['e19_b'][i], out0=a[i], save0=r[i] if save else None,
                         scale=Tt['e19_twos'], shift=Tt['e19_zeros'], B=B, T_in=Tz, T_out=Tz, M=F, C0=F, taps=k3,
                         out_relu=True)
         K.conv_gemm(x0=a[8], w=P['e19_w9'], bias=P['e19_b9'], out0=ws['z_e'], B=B, T_in=Tz, T_out=Tz, M=D, C0=F,

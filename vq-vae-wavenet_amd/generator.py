@@ -8,15 +8,19 @@ import torch
 from . import _lib as L
 
 
-MAX_ROWS = 4   # batch rows of one persistent launch (its LDS budget); larger batches run as several handles
+MAX_ROWS = 4    # batch rows of one persistent handle (its LDS budget); larger batches run as several handles
+MAX_GROUP = 4   # handles of one launch (vqw_ar_decode_run_group_async)
+CU_MARGIN = 8   # CUs left free when handles share a launch: a workgroup of a persistent grid that finds no free CU
+#                 keeps its siblings spinning until their timeout
 
 
 class FastGenerator:
     def __init__(self, model, batch):
         """Uses the model's LIVE variables (call model.use_ema_weights() first to mirror
         generate.py:88-90, which restores the EMA shadows).  Rows of the batch never interact
-        (generate.py:40,103-113), so a batch above MAX_ROWS is cut into independent handles whose
-        persistent kernels (R/8 workgroups each) run side by side on the chip."""
+        (generate.py:40,103-113), so a batch above MAX_ROWS is cut into independent handles; as many of them as the
+        chip has CUs for (one resident workgroup per CU, R/4 or R/8 workgroups per handle) share ONE launch and
+        generate side by side, the rest follow in further waves."""
         self.model, self.B = model, batch
         n_parts = -(-batch // MAX_ROWS)
         base, extra = divmod(batch, n_parts)
@@ -50,6 +54,19 @@ class FastGenerator:
             h = C.c_void_p()
             L.check(L.lib().vqw_ar_decode_create(C.byref(h), C.byref(w), nb))
             self._hs.append(h)
+        # waves of handles that are co-resident by construction: floor((CUs - margin) / workgroups), at most MAX_GROUP
+        nwg = [L.lib().vqw_ar_decode_workgroups(h) for h in self._hs]
+        cus = torch.cuda.get_device_properties(model.dev).multi_processor_count
+        self._waves, i = [], 0
+        while i < len(self._hs):
+            if nwg[i] <= 0:                      # launch-per-phase path: one handle at a time
+                self._waves.append([i]); i += 1
+                continue
+            cap = max(1, min(MAX_GROUP, (cus - CU_MARGIN) // nwg[i]))
+            j = i + 1
+            while j < len(self._hs) and j - i < cap and nwg[j] == nwg[i] and (self._parts[j] > 1) == (self._parts[i] > 1):
+                j += 1
+            self._waves.append(list(range(i, j))); i = j
 
     def reset(self):
         """sess.run(wavenet.init_ops) (generate.py:105)."""
@@ -76,16 +93,23 @@ class FastGenerator:
             if uniforms.shape != (B, n_steps) or uniforms.dtype != torch.float32:
                 raise ValueError('uniforms must be float32 [B][n_steps]')
         encoding = encoding.contiguous()
-        b0 = 0
-        for h, nb in zip(self._hs, self._parts):     # enqueue every part, then wait: the parts generate concurrently
-            rows = slice(b0, b0 + nb)
-            L.check(L.lib().vqw_ar_decode_run_async(
-                h, L.ptr(encoding[rows]), Tz, ratio, n_steps, 0 if mode == 'greedy' else 1,
-                L.ptr(uniforms[rows]) if uniforms is not None else None, L.ptr(audio[rows]), L.ptr(idx[rows]),
-                L.ptr(probs[rows]) if probs is not None else None, L.stream()))
-            b0 += nb
-        for h in self._hs:
-            L.check(L.lib().vqw_ar_decode_wait(h))
+        starts = [sum(self._parts[:i]) for i in range(len(self._parts))]
+        rows = [slice(b0, b0 + nb) for b0, nb in zip(starts, self._parts)]
+        vp = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+        for wave in self._waves:                 # one launch per wave; the waves follow each other
+            hs = (C.c_void_p * len(wave))(*[self._hs[i].value for i in wave])
+            L.check(L.lib().vqw_ar_decode_run_group_async(
+                hs, len(wave), vp([encoding[rows[i]] for i in wave]), Tz, ratio, n_steps, 0 if mode == 'greedy' else 1,
+                vp([uniforms[rows[i]] for i in wave]) if uniforms is not None else None,
+                vp([audio[rows[i]] for i in wave]), vp([idx[rows[i]] for i in wave]),
+                vp([probs[rows[i]] for i in wave]) if probs is not None else None, L.stream())
+                if L.lib().vqw_ar_decode_workgroups(self._hs[wave[0]]) > 0 else
+                L.lib().vqw_ar_decode_run_async(
+                    self._hs[wave[0]], L.ptr(encoding[rows[wave[0]]]), Tz, ratio, n_steps, 0 if mode == 'greedy' else 1,
+                    L.ptr(uniforms[rows[wave[0]]]) if uniforms is not None else None, L.ptr(audio[rows[wave[0]]]),
+                    L.ptr(idx[rows[wave[0]]]), L.ptr(probs[rows[wave[0]]]) if probs is not None else None, L.stream()))
+            for i in wave:
+                L.check(L.lib().vqw_ar_decode_wait(self._hs[i]))
         return (audio, idx, probs) if return_probs else (audio, idx)
 
     def close(self):

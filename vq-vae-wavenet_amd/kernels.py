@@ -332,19 +332,31 @@ def vq_nearest_bwd(z_e, e_k, idx, *, dzq, dzq_bstride, dz_e, demb, cscale, escal
                                        L.ptr(demb), float(cscale), float(escale), B, D, Tz, K, L.stream()))
 
 
+def _need_speakers(spk, table, Cs):
+    if spk.dtype != torch.int64:
+        raise ValueError('speaker ids must be int64, got %s' % spk.dtype)
+    if table.dtype != torch.float32 or table.numel() % Cs != 0 or table.numel() < Cs:
+        raise ValueError('speaker table must be float32 [n_speakers][%d]' % Cs)
+    return table.numel() // Cs
+
+
 def speaker_tile_fwd(table, spk, cond, *, cond_bstride, row0, Cs, Tz):
+    """Ids outside the table read row 0 on the device (model.py:22: one_hot -> argmax); hosts that still hold the ids
+    as Python ints reject them earlier (data.py, generate.py)."""
     B = spk.numel()
     L.require_cuda(table, spk, cond)
+    n_spk = _need_speakers(spk, table, Cs)
     _need(cond, (B - 1) * cond_bstride + (row0 + Cs) * Tz, 'cond')
-    L.check(L.lib().vqw_speaker_tile_fwd(L.ptr(table), L.ptr(spk), L.ptr(cond), cond_bstride, row0, B, Cs, Tz,
+    L.check(L.lib().vqw_speaker_tile_fwd(L.ptr(table), L.ptr(spk), L.ptr(cond), cond_bstride, row0, B, Cs, Tz, n_spk,
                                          L.stream()))
 
 
 def speaker_tile_bwd(dcond, spk, dtable, *, dcond_bstride, row0, Cs, Tz):
     B = spk.numel()
     L.require_cuda(dcond, spk, dtable)
+    n_spk = _need_speakers(spk, dtable, Cs)
     _need(dcond, (B - 1) * dcond_bstride + (row0 + Cs) * Tz, 'dcond')
-    L.check(L.lib().vqw_speaker_tile_bwd(L.ptr(dcond), dcond_bstride, row0, L.ptr(spk), L.ptr(dtable), B, Cs, Tz,
+    L.check(L.lib().vqw_speaker_tile_bwd(L.ptr(dcond), dcond_bstride, row0, L.ptr(spk), L.ptr(dtable), B, Cs, Tz, n_spk,
                                          L.stream()))
 
 

@@ -267,10 +267,15 @@ class VQVAE:
         self.flat.copy_(self.ema)
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, B, T):
-        key = (B, T)
+    def _workspace(self, B, T, train=True):
+        """Buffers of one (B, T) problem, cached.  train=False: only what the encoder + VQ forward pass writes
+        (model.encoding of generate.py:92) -- about 3 KB per audio sample instead of the 136 KB per sample of the
+        training workspace (saved decoder activations of 30 layers + backward buffers)."""
+        key = (B, T, train)
         if key in self._ws:
             return self._ws[key]
+        if not train and (B, T, True) in self._ws:
+            return self._ws[(B, T, True)]
         if self.enc == '64':
             if T % 64 != 0:
                 raise ValueError('length must be a multiple of 64 for Encoder_64 (got %d)' % T)
@@ -285,16 +290,22 @@ class VQVAE:
         ws['labels'] = torch.empty(B, T, dtype=torch.int32, device=dev)
         if self.enc == '64':
             ws['X'] = [e(B, F, t) for t in ws['Tl']]      # BN outputs of encoder layers 0..5
-            ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
-            ws['y6'] = e(B, D, Tz)
-            ws['dX'] = [e(B, F, t) for t in ws['Tl']]
+            if train:
+                ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
+                ws['y6'] = e(B, D, Tz)
+                ws['dX'] = [e(B, F, t) for t in ws['Tl']]
         else:
-            self.magenta.workspace(ws, B, T, dev)
+            self.magenta.workspace(ws, B, T, dev, train)
         ws['z_e'] = e(B, D, Tz)
         ws['idx'] = torch.empty(B, Tz, dtype=torch.int64, device=dev)
         ws['e_k'] = e(B, D, Tz)
         ws['mind'] = e(B, Tz)
         ws['cond'] = e(B, self.Cc, Tz)
+        ws['scale'] = e(6 * F + D)
+        ws['shift'] = e(6 * F + D)
+        if not train:
+            self._ws[key] = ws
+            return ws
         ws['condenc'] = e(B, self.Mall, Tz)
         ws['net'] = [e(B, R, T) for _ in range(L + 1)]
         ws['skip'] = e(B, S, T)
@@ -329,8 +340,6 @@ class VQVAE:
         ws['dcond'] = e(B, self.Cc, Tz)
         ws['dz'] = e(B, D, Tz)
         ws['bskip'] = e(S)
-        ws['scale'] = e(6 * F + D)
-        ws['shift'] = e(6 * F + D)
         ws['dscale'] = e(6 * F + D)
         self._ws[key] = ws
         return ws
@@ -702,11 +711,25 @@ class VQVAE:
 
     # ------------------------------------------------------------------ generation
     def encode(self, x, spk):
-        """model.encoding of generate.py:92: [B][Cc][Tz] (channel-major)."""
-        B, T = x.shape
-        ws = self._workspace(B, T)
-        self._encode(x, spk, ws, save=False)
-        return ws['cond'].clone()
+        """model.encoding of generate.py:92: [B][Cc][Tz] (channel-major).  x [B][T], or ONE utterance [1][T] with
+        B speaker ids (generate.py:40 repeats the utterance per speaker: the encoder and VQ then run once and only the
+        speaker rows of the condition differ)."""
+        Bx, T = x.shape
+        B = spk.numel()
+        if Bx != B and Bx != 1:
+            raise ValueError('encode: %d utterances for %d speaker ids' % (Bx, B))
+        ws = self._workspace(Bx, T, train=False)
+        self._encode(x, spk[:Bx].contiguous(), ws, save=False)
+        if Bx == B:
+            return ws['cond'].clone()
+        cond = ws['cond'].repeat(B, 1, 1)
+        K.speaker_tile_fwd(self.P['speaker_embedding'], spk, cond, cond_bstride=self.Cc * ws['Tz'], row0=self.D,
+                           Cs=self.Cs, Tz=ws['Tz'])
+        return cond
+
+    def free_workspaces(self):
+        """Drop the cached (B, T) workspaces (a long-running host changing shapes would otherwise keep them all)."""
+        self._ws.clear()
 
     def state_dict(self):
         return {'flat': self.flat, 'ema': self.ema, 'adam_m': self.adam_m, 'adam_v': self.adam_v,
