@@ -68,12 +68,18 @@ def test_bench_workload_full_step_matches_oracle(pkg):
         e = l2err(got[name], gref)
         worst = max(worst, (name, e), key=lambda p: p[1])
         assert e < 5e-3, 'grad %s rel L2 err %.3e' % (name, e)
-    # TF-Adam + EMA over the flat buffer at the full parameter count (model.py:116-128).  The first Adam step moves
-    # every parameter by lr * g / (|g| + eps'): where g is at rounding level its sign is not determined, hence 1e-4
-    # (the bar of tests/test_model_gpu.py::run_parity), observed 1.5e-5 on the smallest tensor
+    # TF-Adam + EMA over the flat buffer at the full parameter count (model.py:116-128).  The first Adam step moves a
+    # parameter by u = lr g / (|g| + eps): du/dg = lr eps / (|g| + eps)^2, so a relative gradient error d moves u by
+    # less than lr d eps / |g|.  Elements with |g| > 1e-5 (eps = 1e-8) must therefore agree to 1e-3 lr; every element
+    # stays within the step bound 2 lr of the oracle's (where g is at rounding level its sign is not determined).
     newp = model.named_parameters()
-    for name, pref in P.items():
-        assert l2err(newp[name], pref) < 1e-4, 'param %s after the step' % name
+    lr = model.lr_at(0)
+    for name, gref in grads.items():
+        diff = (newp[name].cpu() - P[name]).abs()
+        assert float(diff.max()) <= 2.001 * lr, 'param %s moved by more than the step bound' % name
+        firm = gref.abs() > 1e-5
+        if firm.any():
+            assert float(diff[firm].max()) <= 1e-3 * lr, 'param %s after the step: %.3e' % (name, float(diff[firm].max()))
     print('bench-shape step: loss %.6f (oracle %.6f), worst grad %s %.2e' % (loss, out['loss'].item(), *worst))
 
 

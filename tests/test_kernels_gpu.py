@@ -239,6 +239,40 @@ def test_named_wrappers_causal(K, pkg):
     close(btc(y2), R.conv1d_v2(x, w, b, dilations=dil, stride=2), what='wrapper fwd stride 2')
 
 
+def test_named_wrappers_pointwise(K, pkg):
+    """vqw_pointwise_gemm_{fwd,dgrad,wgrad} (wavenet_ops.py:132-136 / 147-160: the 1x1 convs) through the C ABI:
+    plain, relu prologue, accumulate-into-output; input and weight gradients against torch autograd."""
+    L = pkg._lib
+    B, T, Cin, Cout = 2, 320, 64, 96
+    x, w, b = rnd(B, T, Cin, seed=11), rnd(Cin, Cout, seed=12, s=0.1), rnd(Cout, seed=13)
+    xb, wb, bb = bct(x), g(w), g(b)
+    y = torch.full((B, Cout, T), float('nan'), device=DEV)
+    L.check(L.lib().vqw_pointwise_gemm_fwd(L.ptr(xb), L.ptr(wb), L.ptr(bb), L.ptr(y), B, Cin, Cout, T, 0, 0, L.stream()))
+    close(btc(y), x @ w + b, what='pointwise fwd')
+    L.check(L.lib().vqw_pointwise_gemm_fwd(L.ptr(xb), L.ptr(wb), None, L.ptr(y), B, Cin, Cout, T, 1, 0, L.stream()))
+    close(btc(y), torch.relu(x) @ w, what='pointwise fwd, relu prologue, no bias')
+    acc0 = rnd(B, T, Cout, seed=14)
+    acc = bct(acc0)
+    L.check(L.lib().vqw_pointwise_gemm_fwd(L.ptr(xb), L.ptr(wb), L.ptr(bb), L.ptr(acc), B, Cin, Cout, T, 0, 1, L.stream()))
+    close(btc(acc), acc0 + x @ w + b, what='pointwise fwd, accumulate (skip += ...)')
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    dy = rnd(B, T, Cout, seed=15)
+    (torch.relu(xr) @ wr).backward(dy)
+    dyb = bct(dy)
+    wT = torch.empty(Cout, Cin, device=DEV)
+    K.transpose(wb, wT, 1, Cin, Cout)
+    dx = torch.empty(B, Cin, T, device=DEV)
+    L.check(L.lib().vqw_pointwise_gemm_dgrad(L.ptr(dyb), L.ptr(wT), L.ptr(dx), B, Cin, Cout, T, L.stream()))
+    close(btc(dx) * (x > 0), xr.grad, what='pointwise dgrad (relu mask applied by the caller)')
+    dw = torch.zeros(Cin, Cout, device=DEV)
+    L.check(L.lib().vqw_pointwise_gemm_wgrad(L.ptr(xb), L.ptr(dyb), L.ptr(dw), B, Cin, Cout, T, 1, L.stream()))
+    close(dw, wr.grad, rtol=5e-4, atol=5e-4, what='pointwise wgrad, relu prologue')
+    L.check(L.lib().vqw_pointwise_gemm_wgrad(L.ptr(xb), L.ptr(dyb), L.ptr(dw), B, Cin, Cout, T, 1, L.stream()))
+    close(dw, 2 * wr.grad, rtol=5e-4, atol=5e-4, what='pointwise wgrad accumulates into dw')
+    assert L.lib().vqw_pointwise_gemm_fwd(None, L.ptr(wb), None, L.ptr(y), B, Cin, Cout, T, 0, 0, L.stream()) != 0
+    assert b'null' in L.lib().vqw_last_error().lower() or L.lib().vqw_last_error()
+
+
 def test_bad_arguments_return_errors_not_faults(K, pkg):
     L = pkg._lib
     x = torch.zeros(1, 24, 64, device=DEV)

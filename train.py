@@ -22,19 +22,15 @@ sys.path.insert(0, ROOT)
 
 
 def display_time(t, second):
-    """utils.py:49-67."""
-    minute, hour = None, None
+    """Console suffix in the reference's format (utils.py:49-67): batch time, then the ETA as seconds, `Nm S.SSSs` above
+    one minute, `Nh Nm S.SSSs` above one hour of minutes (the reference's thresholds are strict: 60 s prints as seconds)."""
+    eta = '%.3fs' % second
     if second > 60:
-        minute = second // 60
-        second %= 60
+        minute, second = divmod(second, 60)
+        eta = '%dm %.3fs' % (minute, second)
         if minute > 60:
-            hour = minute // 60
-            minute %= 60
-    if hour is not None:
-        return ' [BATCH %.3fs / ETA %dh %dm %.3fs]     ' % (t, hour, minute, second)
-    if minute is not None:
-        return ' [BATCH %.3fs / ETA %dm %.3fs]     ' % (t, minute, second)
-    return ' [BATCH %.3fs / ETA %.3fs]     ' % (t, second)
+            eta = '%dh %dm %.3fs' % (minute // 60, minute % 60, second)
+    return ' [BATCH %.3fs / ETA %s]     ' % (t, eta)
 
 
 def main():

@@ -817,14 +817,9 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
                 (!d.save0 || aligned16(d.save0)) && (!d.save1 || aligned16(d.save1)))
                    ? 1 : 0;
 
-    static const int dma_env = [] { const char* e = getenv("VQW_CONV_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
-    a.use_dma = dma_env;
+    a.use_dma = vqw_env_enabled("VQW_CONV_DMA");
     hipStream_t st = static_cast<hipStream_t>(s);
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    const int cus = vqw_device_cus();
     const bool gate = d.epilogue == VQW_EPI_GATE;
     auto nblocks = [&](int t) {
         const int mt = t / 10, nt = t % 10;
@@ -871,7 +866,7 @@ extern "C" int vqw_conv_gemm(const vqw_conv_desc* dp, vqw_stream_t s) {
     // gives the last columns of every row to tiles half as wide, appended to the same grid: they start as the
     // big blocks of the last full round retire and spread over all CUs.  Explicit form of `tile`:
     // main + 10000*(main-tile columns given to the half-width tiles); VQW_CONV_TAIL=0 disables the auto choice.
-    static const int tail_env = [] { const char* e = getenv("VQW_CONV_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int tail_env = vqw_env_enabled("VQW_CONV_TAIL");
     const int main_tile = tile % 100;
     int tail_nt = tile / 10000;
     const int mtm = main_tile / 10, ntm = main_tile % 10;

@@ -158,13 +158,10 @@ extern "C" int vqw_vq_nearest_bwd(const float* z_e, const float* e_k, const int6
     const size_t n = (size_t)B * D * Tz;
     const size_t lds = (size_t)K * D * sizeof(float);
     if (demb && K > 0 && lds <= 144 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    144 * 1024) != hipSuccess)
-                return vqw_set_error("vqw_vq_nearest_bwd: hipFuncSetAttribute failed");
-            attr_set = true;
-        }
+        // per call: the attribute belongs to the current device's copy of the kernel (no process-wide "done" flag)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                144 * 1024) != hipSuccess)
+            return vqw_set_error("vqw_vq_nearest_bwd: hipFuncSetAttribute failed");
         int g = (int)((n + 256 * 16 - 1) / (256 * 16));   // ~16 elements per thread: few table flushes
         if (g < 1) g = 1;
         if (g > 64) g = 64;

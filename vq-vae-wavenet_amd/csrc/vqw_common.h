@@ -40,6 +40,8 @@ __device__ __forceinline__ void vqw_buf_load_lds16(__amdgpu_buffer_rsrc_t r, flo
 #endif
 
 int vqw_set_error(const char* fmt, ...);
+int vqw_device_cus();                     // CU count of the calling thread's current device
+int vqw_env_enabled(const char* name);    // 0 only if the environment variable starts with '0'
 
 #define VQW_CHECK(cond, ...)                           \
     do {                                               \

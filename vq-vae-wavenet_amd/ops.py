@@ -6,8 +6,10 @@ Encoder/encoder_ops.py:46-70, Decoder/decoder_ops.py:39-43.  Tensors are channel
 calls libvqwave and transposes back (the assembled model in model.py stays in (B,C,T)
 throughout).  Where the reference creates variables implicitly (tf.get_variable) the kernel /
 bias tensors are explicit arguments with the reference's shapes: kernel [k, Cin, Cout].
-The per-sample `fast_*` ops (wavenet_ops.py:163-267) are stateful queue programs in the
-reference; their counterpart is generator.FastGenerator (vqw_ar_decode_*).
+The reference's own signatures (variables created implicitly under a variable scope), the
+classes Encoder_64 / Wavenet / WavenetDecoder and the per-sample `fast_*` queue ops
+(wavenet_ops.py:163-267) live in graph.py on top of these; the fused generator is
+generator.FastGenerator (vqw_ar_decode_*).
 """
 import torch
 
@@ -130,6 +132,11 @@ def _keras_conv1d(net, kernel, bias, stride, relu):
     L.check(L.lib().vqw_conv1d_same_fwd(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), B, Cin, Cout, T,
                                         To, k, stride, total // 2, int(relu), L.stream()))
     return _btc(y)
+
+
+def keras_conv1d(net, kernel, bias, stride=1, relu=False):
+    """tf.keras.layers.Conv1D(padding='same' -- or 'valid' with k=1) as used by Encoder/encoder.py:15-25."""
+    return _keras_conv1d(net, kernel, bias, stride, relu)
 
 
 def conv_3_768(net, kernel, bias, relu='relu'):
