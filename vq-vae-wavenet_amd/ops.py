@@ -128,6 +128,10 @@ def _keras_conv1d(net, kernel, bias, stride, relu):
     To = -(-T // stride)
     total = max((To - 1) * stride + k - T, 0)       # TF 'SAME' 
     y = torch.empty(B, Cout, To, device=net.device)
+    if Cin == 1:        # the first encoder layer (encoder.py:15 on raw audio): VALU kernel, HBM-bound by its output
+        K.conv_cin1_fwd(net[:, :, 0].contiguous(), kernel.reshape(k, Cout).contiguous(), bias, y, k=k, stride=stride,
+                        offset=-(total // 2), relu=relu)
+        return _btc(y)
     x = _bct(net)
     L.check(L.lib().vqw_conv1d_same_fwd(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), B, Cin, Cout, T,
                                         To, k, stride, total // 2, int(relu), L.stream()))
