@@ -312,15 +312,31 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
  * fp32 accumulators (DESIGN.md 3.2b for the error analysis and measurements).
  * Plane layout: [plane 0..1][channel chunk of 8][row][8 fp16] (16-byte entries); 2 * rows * channels bytes each.    */
 
-/* scale * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0.  scale: 1 for activations, a power of two
- * that lifts a gradient tensor into fp16's range (undone through w_scale_inv of the consumer) */
+/* Range guards.  The leading plane of scale * x must stay inside fp16 (|.| <= 65504).  Scales are powers of two held in
+ * DEVICE memory, chosen from measured max-abs values with no host round trip:
+ *   vqw_f16x3_amax           amax[i] = max(amax[i], bits(max |x_i|)) over `count` strided matrices [rows][cols]
+ *                            (row stride ld, matrix stride mstride); raises *flag on inf / NaN;
+ *   vqw_f16x3_update_scales  scale[i] = 2^k with amax[i] * scale[i] in [2^(target_exp-1), 2^target_exp); a slot whose
+ *                            amax is 0 keeps its scale; reset != 0 zeroes amax[] for the next collection.
+ * Kernels that WRITE planes take the scale from a device slot (`*_scale` / `scale_dev` below), report the max-abs of
+ * their fp32 values into `out_amax` (the scale of the NEXT step comes from it) and raise *flag (|= 1) when an element
+ * leaves fp16's range or is not finite: the host then repeats the step on the fp32 engine (model.py).  Every guard
+ * pointer may be NULL (fixed host-side scales, no checks).                                                          */
+int vqw_f16x3_amax(const float* x, int64_t rows, int cols, int64_t ld, int64_t mstride, int count, uint32_t* amax,
+                   int32_t* flag, vqw_stream_t s);
+int vqw_f16x3_update_scales(uint32_t* amax, float* scale, int n, int target_exp, int reset, int32_t* flag, vqw_stream_t s);
+
+/* scale * scale_dev[0] * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0.  scale: 1 for activations, a
+ * power of two that lifts a gradient tensor into fp16's range (undone through w_scale_inv / x_scale of the consumer) */
 int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC,
+                                const float* scale_dev, uint32_t* amax, int32_t* flag,
                                 vqw_stream_t s);   /* planes hold KC chunks per plane, x goes to chunks kc0.. (0, 0: KC = C/8) */
 /* w [ks][R][ldw] fp32 (kernel[k, Cin, Cout]: filter columns 0..R-1, gate columns R..2R-1), multiplied by `scale`
  * (a power of two that lifts the residual plane into fp16's normal range, e.g. 256) -> planes [2][ks*R/8][2R][8]
  * with the output channels in the kernel's block order; R % 128 == 0.  `count` layers stored back to back (w: ks*R*ldw
  * floats apart, planes: 2*ks*R*2R halves apart) are packed by one launch */
-int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count, vqw_stream_t s);
+int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count,
+                                const float* scale_dev, vqw_stream_t s);   /* planes hold scale * scale_dev[0] * w */
 
 typedef struct vqw_f16x3_gate_desc {
     const void* xp;      /* activation planes of the layer input [B][R][T]                  */
@@ -336,13 +352,16 @@ typedef struct vqw_f16x3_gate_desc {
     float w_scale_inv;   /* 1 / scale of the weight planes                                  */
     int32_t out_planes_kc0, out_planes_KC;  /* out_planes holds KC chunks of 8 channels per plane, this layer's start at
                                              * chunk kc0 (several layers side by side); 0, 0 = exactly this layer's R/8 */
+    const float* x_scale;  /* device scalars (or NULL = 1): the scales xp and wp were written with; the accumulators */
+    const float* w_scale;  /* are multiplied by w_scale_inv / (x_scale * w_scale)                                    */
 } vqw_f16x3_gate_desc;
 /* T % 256 == 0, R % 128 == 0, (T / cond_T) % 32 == 0; tap j reads x[t - (ks-1-j)*dilation], zero before t = 0 */
 int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
 
 /* w [K][ldw] fp32 (row k, column m), times `scale` -> planes [2][K/8][M][8]; K % 8 == 0; `count` matrices back to back
  * (w: K*ldw floats apart, planes: 2*K*M halves apart) */
-int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count, vqw_stream_t s);
+int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count,
+                           const float* scale_dev, vqw_stream_t s);
 
 /* The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
  * skip[b][m][t] += (W g)[m] + bias[m] for m < S;  net_out[b][c][t] = net_in[b][c][t] + (W g)[S+c] + bias[S+c],
@@ -370,6 +389,11 @@ typedef struct vqw_f16x3_out_desc {
                             * net_out = dpre [B][2R][T] = {dg*sg*(1-th^2), dg*th*sg*(1-sg)} with aux0 = th, aux1 = sg [B][R][T] */
     const float* aux0;
     const float* aux1;
+    const float* x_scale;  /* device scalars (or NULL = 1) of xp / wp: accumulators times w_scale_inv / (x_scale * w_scale) */
+    const float* w_scale;
+    const float* out_scale; /* device scalar (or NULL = 1): net_out_planes hold plane_scale * out_scale * net_out   */
+    uint32_t* out_amax;    /* atomicMax of the bit pattern of max |net_out| (or NULL)                                */
+    int32_t* flag;         /* |= 1 when plane_scale * out_scale * |net_out| > 65504 or net_out is not finite (or NULL) */
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 

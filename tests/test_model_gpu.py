@@ -156,6 +156,87 @@ def test_default_width_gate_f16x3(pkg, monkeypatch, mode):
     print('worst grad', worst)
 
 
+def _guarded_model(pkg, monkeypatch, P, m, w):
+    monkeypatch.setenv('VQW_ENGINE', 'f16x3')
+    monkeypatch.delenv('VQW_GATE_F16X3', raising=False)
+    model = build(pkg, m, w, 109, P)
+    assert model.x3_guard and model.gbwd_f16x3
+    return model
+
+
+def _check_step(model, out, grads, ws, grad_tol=5e-3):
+    loss, recon, vq, commit = model.losses(ws)
+    np.testing.assert_allclose(loss, out['loss'].item(), rtol=2e-5)
+    np.testing.assert_allclose(recon, out['reconstruction_loss'].item(), rtol=2e-5)
+    assert torch.equal(ws['idx'].cpu(), out['q'])
+    got = model.named_gradients()
+    for name, gref in grads.items():
+        assert l2err(got[name], gref) < grad_tol, 'grad %s rel L2 err %.3e' % (name, l2err(got[name], gref))
+
+
+def test_guarded_f16x3_engine_three_steps(pkg, monkeypatch):
+    """VQW_ENGINE=f16x3: the decoder's contractions as 3-term fp16-plane products with device-side range
+    guards, against the oracle at the fp32 engine's tolerances for three consecutive steps: step 1 runs with the
+    start-up scales, steps 2 and 3 with scales derived on the device from the max-abs values of the step before."""
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    P = M.init_params(m, w, 109, seed=3, randomize_all=True)
+    x, spk, _ = M.synthetic_batch(1, 1024, 109, 1234)
+    model = _guarded_model(pkg, monkeypatch, P, m, w)
+    xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
+    st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
+    for step in range(3):
+        out, grads = M.train_step(x, spk, P, m, w, st, step)
+        ws = model.train_step(xd, sd)
+        assert ws['x3_used']
+        _check_step(model, out, grads, ws)
+    assert model.x3_steps == 3 and model.x3_fallbacks == 0
+    sc = model.x3_scale.cpu()
+    assert torch.equal(sc, torch.exp2(torch.round(torch.log2(sc)))), 'scales must be powers of two'
+    amax_scaled = 0.06 * sc[model.SL['WG']]          # |gate kernels| <= sqrt(3 / 768) = 0.0625 (+ nothing: biases are separate)
+    assert 2 ** 12 <= float(amax_scaled) < 2 ** 15
+
+
+@pytest.mark.parametrize('what', ['activations', 'weights', 'gradients', 'nan'])
+def test_guarded_f16x3_engine_adversarial_ranges(pkg, monkeypatch, what):
+    """Operands the fixed scales of the development ladder could not hold: |net| > 65504 (preprocess kernel x 3e5),
+    |w| > 255 (one gate kernel x 1e4), gradients above 2^-20 * 65504 (both head kernels x 8), a NaN weight.
+    Weights always get an exact scale; activations / gradients trip the range flag on the first step, the step is repeated
+    on the fp32 engine (results = the oracle's), and the following step runs on the fp16x3 engine again with measured
+    scales -- still at the fp32 engine's tolerances."""
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    P = M.init_params(m, w, 109, seed=3, randomize_all=True)
+    if what == 'activations':      # a residual stream of ~3e5 with gate kernels small enough to keep the gates unsaturated
+        P['decoder/preprocess/kernel'] *= 3e5
+        for name in P:
+            if name.endswith('/gated/kernel'):
+                P[name] *= 1e-5
+    elif what == 'weights':
+        P['decoder/cycle_2/layer_3/gated/kernel'] *= 1e4
+    elif what == 'gradients':
+        P['decoder/postprocess2/kernel'] *= 8.0
+        P['decoder/postprocess1/kernel'] *= 8.0
+    x, spk, _ = M.synthetic_batch(1, 1024, 109, 1234)
+    model = _guarded_model(pkg, monkeypatch, P, m, w)
+    xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
+    if what == 'nan':
+        model.P['out_w'][7, 3, 5] = float('nan')
+        ws = model.train_step(xd, sd)
+        assert model.x3_fallbacks == 1 and not ws['x3_used']          # detected, repeated on the fp32 engine
+        assert not np.isfinite(model.losses(ws)[0])                     # which reports the NaN as the reference would
+        return
+    st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
+    used = []
+    for step in range(3):
+        out, grads = M.train_step(x, spk, P, m, w, st, step)
+        ws = model.train_step(xd, sd)
+        used.append(bool(ws['x3_used']))
+        _check_step(model, out, grads, ws)
+    if what == 'weights':
+        assert model.x3_fallbacks == 0 and used == [True, True, True]
+    else:
+        assert model.x3_fallbacks >= 1 and not used[0] and used[-1], (model.x3_fallbacks, used)
+
+
 def test_data_parallel_shards_sum_to_full_batch(pkg):
     """Two 'ranks' with half the batch each: mean of their flat gradients == full-batch
     gradient (what the RCCL all-reduce + 1/world scaling computes)."""

@@ -59,6 +59,7 @@ class F16x3GateDesc(C.Structure):
         ('out_planes', _fp), ('cond_bstride', C.c_int64),
         ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('ks', C.c_int32), ('dilation', C.c_int32),
         ('cond_T', C.c_int32), ('w_scale_inv', C.c_float), ('out_planes_kc0', C.c_int32), ('out_planes_KC', C.c_int32),
+        ('x_scale', _fp), ('w_scale', _fp),
     ]
 
 
@@ -71,6 +72,7 @@ class F16x3OutDesc(C.Structure):
         ('ks', C.c_int32), ('dilation', C.c_int32), ('dir', C.c_int32),
         ('planes_kc0', C.c_int32), ('planes_KC', C.c_int32), ('plane_scale', C.c_float), ('epi', C.c_int32),
         ('aux0', _fp), ('aux1', _fp),
+        ('x_scale', _fp), ('w_scale', _fp), ('out_scale', _fp), ('out_amax', _fp), ('flag', _fp),
     ]
 
 _i, _f, _sz, _i64 = C.c_int, C.c_float, C.c_size_t, C.c_int64
@@ -114,10 +116,12 @@ SIGNATURES = {
                                            C.POINTER(_fp), C.POINTER(_fp), _fp]),
     'vqw_ar_decode_workgroups': (_i, [_fp]),
     'vqw_ar_decode_destroy': (_i, [_fp]),
-    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _i, _fp]),
-    'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),
+    'vqw_f16x3_amax': (_i, [_fp, _i64, _i, _i64, _i64, _i, _fp, _fp, _fp]),
+    'vqw_f16x3_update_scales': (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
+    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _i, _fp, _fp, _fp, _fp]),
+    'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _fp]),
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),
-    'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp]),
+    'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _fp]),
     'vqw_f16x3_out_conv': (_i, [C.POINTER(F16x3OutDesc), _fp]),
 }
 

@@ -37,26 +37,100 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& p0, uint4& p1
     p1 = make_uint4(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16), b[4] | ((unsigned)b[5] << 16), b[6] | ((unsigned)b[7] << 16));
 }
 
-// x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16
-__global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T, float scale, int kc0, int KC) {
+// ---- range guards: the leading plane of scale * x must stay inside fp16 (|.| <= 65504).  Scales are
+// powers of two held in DEVICE memory (chosen from measured max-abs values, vqw_f16x3_update_scales); a kernel that
+// writes planes reports the max-abs of its fp32 values (atomicMax on the bit pattern: monotonic for non-negative
+// floats) and raises `flag` when an element leaves the range or is not finite -- the host then repeats the step on the
+// fp32 engine.
+constexpr float F16_MAX = 65504.0f;
+__device__ __forceinline__ float dev_scale(const float* p) { return p ? *p : 1.0f; }
+// 1 / (sa * sb) for powers of two (v_rcp_f32 is exact on them)
+__device__ __forceinline__ float inv_scales(float host_inv, const float* sa, const float* sb) {
+    return (sa || sb) ? host_inv * __builtin_amdgcn_rcpf(dev_scale(sa) * dev_scale(sb)) : host_inv;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// called by all lanes of a wave: amax of the wave's fp32 values (`m`, NaN-propagating through `bad`), range check of m * ps
+__device__ __forceinline__ void guard_report(float m, bool bad, float ps, unsigned* amax, int* flag) {
+    if (!amax && !flag) return;
+    const float wm = wave_max(m);
+    const bool wbad = __any(bad || !(m * ps <= F16_MAX));
+    if ((threadIdx.x & 63) == 0) {
+        if (amax) atomicMax(amax, __float_as_uint(wm));
+        if (flag && wbad) atomicOr(flag, 1);
+    }
+}
+
+// x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16 of scale * scale_dev[0] * x
+__global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T, float scale, int kc0, int KC,
+                                 const float* __restrict__ scale_dev, unsigned* amax, int* flag) {
     const size_t NB = (size_t)B * T;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NB * (C / 8)) return;
-    const size_t row = i % NB;
-    const int kc = (int)(i / NB);
-    const int b = (int)(row / T), t = (int)(row % T);
-    float v[8];
+    const bool live = i < NB * (C / 8);
+    const float sc = scale * dev_scale(scale_dev);
+    float m = 0.0f;
+    bool bad = false;
+    if (live) {
+        const size_t row = i % NB;
+        const int kc = (int)(i / NB);
+        const int b = (int)(row / T), t = (int)(row % T);
+        float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = x[((size_t)b * C + kc * 8 + e) * T + t] * scale;
-    uint4 p0, p1;
-    split8(v, p0, p1);
-    planes[(size_t)(kc0 + kc) * NB + row] = p0;
-    planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
+        for (int e = 0; e < 8; ++e) {
+            const float xv = x[((size_t)b * C + kc * 8 + e) * T + t];
+            v[e] = xv * sc;
+            bad |= !(fabsf(xv) <= 3.0e38f);
+            m = fmaxf(m, fabsf(xv));
+        }
+        uint4 p0, p1;
+        split8(v, p0, p1);
+        planes[(size_t)(kc0 + kc) * NB + row] = p0;
+        planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
+    }
+    guard_report(m, bad, sc, amax, flag);
+}
+
+// max |x| over `count` strided matrices [rows][cols] (row stride ld, matrix stride mstride) -> amax[blockIdx.y]
+__global__ void amax_kernel(const float* __restrict__ x, long rows, int cols, long ld, long mstride, unsigned* amax, int* flag) {
+    const float* xb = x + (size_t)blockIdx.y * mstride;
+    const size_t n = (size_t)rows * cols;
+    float m = 0.0f;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = xb[(i / cols) * ld + (i % cols)];
+        bad |= !(fabsf(v) <= 3.0e38f);
+        m = fmaxf(m, fabsf(v));
+    }
+    guard_report(m, bad, 0.0f, amax + blockIdx.y, flag);
+}
+
+// scale[i] = 2^(target_exp - 1 - floor(log2(amax[i]))): amax * scale in [2^(target_exp-1), 2^target_exp); a slot that saw
+// nothing (amax == 0) keeps its scale; reset: amax[i] = 0 afterwards (the next step collects afresh)
+__global__ void update_scales_kernel(unsigned* amax, float* scale, int n, int target_exp, int reset, int* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned b = amax[i];
+    if (b >= 0x7f800000u) {                  // inf / NaN was seen
+        if (flag) atomicOr(flag, 1);
+    } else if (b != 0) {
+        int e = (int)(b >> 23) - 127;        // floor(log2(amax)); denormals: -127
+        int se = target_exp - 1 - e;
+        se = se > 100 ? 100 : (se < -100 ? -100 : se);
+        scale[i] = __uint_as_float((unsigned)(se + 127) << 23);
+    } else if (scale[i] == 0.0f) {
+        scale[i] = 1.0f;
+    }
+    if (reset) amax[i] = 0;
 }
 
 // w [ks][R][ldw] (kernel[k, Cin, Cout], filter columns 0..R-1, gate columns R..2R-1) -> planes [2][ks*R/8][2R][8],
 // rows in block order: row m' = 256 mt + i is filter channel 128 mt + i (i < 128) or gate channel 128 mt + i - 128
-__global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int ks, int R, int ldw, float scale) {
+__global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int ks, int R, int ldw, float scale,
+                                   const float* __restrict__ scale_dev) {
+    scale *= dev_scale(scale_dev);
     const int M = 2 * R, KC = ks * R / 8;
     w += (size_t)blockIdx.y * ks * R * ldw;          // one layer per grid row
     planes += (size_t)blockIdx.y * 2 * KC * M;
@@ -76,7 +150,9 @@ __global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restric
 }
 
 // w [K][ldw] fp32 (columns = output rows m) -> planes [2][K/8][M][8], natural row order
-__global__ void pack_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int K, int M, int ldw, float scale) {
+__global__ void pack_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int K, int M, int ldw, float scale,
+                              const float* __restrict__ scale_dev) {
+    scale *= dev_scale(scale_dev);
     const int KC = K / 8;
     w += (size_t)blockIdx.y * K * ldw;
     planes += (size_t)blockIdx.y * 2 * KC * M;
@@ -243,6 +319,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
     const int tcol = t0 + 64 * wv + l31;
     const int tz0 = (t0 + 64 * wv) / a.ratio, tz1 = (t0 + 64 * wv + 32) / a.ratio;   // 32 | ratio: one frame per tile row
     const bool s0 = d.save0 != nullptr, s1 = d.save1 != nullptr;
+    const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -267,8 +344,8 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float xf = acc[i][j][v4 * 4 + e] * d.w_scale_inv + addf[e][j];
-                    const float xg = acc[i + 4][j][v4 * 4 + e] * d.w_scale_inv + addg[e][j];
+                    const float xf = acc[i][j][v4 * 4 + e] * winv + addf[e][j];
+                    const float xg = acc[i + 4][j][v4 * 4 + e] * winv + addg[e][j];
                     const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * xf) + 1.0f);
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-xg));
                     const int o = e * T + 32 * j;
@@ -310,6 +387,10 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
     const bool hb = d.bias != nullptr;
     const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);
     const int tcol = t0 + 64 * wv + l31;
+    const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
+    const float ps = (d.plane_scale > 0.0f ? d.plane_scale : 1.0f) * dev_scale(d.out_scale);
+    float gmax = 0.0f;
+    bool gbad = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -331,16 +412,20 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    nq[j][e] = old[j][e] + (acc[i][j][v4 * 4 + e] * d.w_scale_inv + bq[e]);
+                    nq[j][e] = old[j][e] + (acc[i][j][v4 * 4 + e] * winv + bq[e]);
                     pout[e * T + 32 * j] = nq[j][e];
                 }
             if (!is_skip && d.net_out_planes) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gmax = fmaxf(gmax, fabsf(nq[j][e])); gbad |= !(fabsf(nq[j][e]) <= 3.0e38f); }
                     store_plane_quad(d.net_out_planes, d.planes_KC > 0 ? d.planes_KC : R / 8, a.NB, d.planes_kc0 + (m0 - S) / 8,
-                                     n0 + 64 * wv + 32 * j + l31, lhi, nq[j], d.plane_scale > 0.0f ? d.plane_scale : 1.0f);
+                                     n0 + 64 * wv + 32 * j + l31, lhi, nq[j], ps);
+                }
             }
         }
+    if (!is_skip && d.net_out_planes) guard_report(gmax, gbad, ps, d.out_amax, d.flag);
 }
 
 // Gate backward (the transpose of gated_cnn's tanh * sigmoid, wavenet_ops.py:112-113, behind the transposed 1x1 convs):
@@ -364,7 +449,10 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a)
         f16x3_mainloop(acc, smem, g, wv, lane);
     }
     const int tcol = t0 + 64 * wv + l31;
-    const float ps = d.plane_scale > 0.0f ? d.plane_scale : 1.0f;
+    const float ps = (d.plane_scale > 0.0f ? d.plane_scale : 1.0f) * dev_scale(d.out_scale);
+    const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
+    float gmax = 0.0f;
+    bool gbad = false;
     const int PKC = d.planes_KC > 0 ? d.planes_KC : 2 * R / 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -386,9 +474,11 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a)
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float dg = acc[i][j][v4 * 4 + e] * d.w_scale_inv;
+                    const float dg = acc[i][j][v4 * 4 + e] * winv;
                     qf[j][e] = dg * sg[j][e] * (1.0f - th[j][e] * th[j][e]);
                     qg[j][e] = dg * th[j][e] * sg[j][e] * (1.0f - sg[j][e]);
+                    gmax = fmaxf(gmax, fmaxf(fabsf(qf[j][e]), fabsf(qg[j][e])));
+                    gbad |= !(fabsf(dg) <= 3.0e38f);
                     pf[e * T + 32 * j] = qf[j][e];
                     pq[e * T + 32 * j] = qg[j][e];
                 }
@@ -400,40 +490,62 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a)
                 }
             }
         }
+    if (d.net_out_planes) guard_report(gmax, gbad, ps, d.out_amax, d.flag);
 }
 
 }  // namespace
 
 extern "C" {
 
-int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC, vqw_stream_t s_) {
+int vqw_f16x3_amax(const float* x, int64_t rows, int cols, int64_t ld, int64_t mstride, int count, uint32_t* amax, int32_t* flag, vqw_stream_t s_) {
+    VQW_CHECK(x && amax, "vqw_f16x3_amax: null pointer");
+    VQW_CHECK(rows > 0 && cols > 0 && ld >= cols && count >= 1 && count <= 65535, "vqw_f16x3_amax: bad shape (rows=%lld cols=%d ld=%lld count=%d)", (long long)rows, cols, (long long)ld, count);
+    const size_t n = (size_t)rows * cols;
+    unsigned g = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(amax_kernel, dim3(g, count), dim3(256), 0, (hipStream_t)s_, x, (long)rows, cols, (long)ld, (long)mstride, amax, flag);
+    VQW_LAUNCH_CHECK("vqw_f16x3_amax");
+    return 0;
+}
+
+int vqw_f16x3_update_scales(uint32_t* amax, float* scale, int n, int target_exp, int reset, int32_t* flag, vqw_stream_t s_) {
+    VQW_CHECK(amax && scale && n > 0, "vqw_f16x3_update_scales: null pointer");
+    VQW_CHECK(target_exp >= 1 && target_exp <= 15, "vqw_f16x3_update_scales: target_exp must be in 1..15 (fp16 holds |x| < 2^16)");
+    hipLaunchKernelGGL(update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)s_, amax, scale, n, target_exp, reset, flag);
+    VQW_LAUNCH_CHECK("vqw_f16x3_update_scales");
+    return 0;
+}
+
+int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC,
+                                const float* scale_dev, uint32_t* amax, int32_t* flag, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(x && planes, "vqw_f16x3_split_activations: null pointer");
     VQW_CHECK(B > 0 && T > 0 && C > 0 && C % 8 == 0, "vqw_f16x3_split_activations: C must be a positive multiple of 8 (got %d)", C);
     if (KC <= 0) { KC = C / 8; kc0 = 0; }
     VQW_CHECK(kc0 >= 0 && kc0 + C / 8 <= KC, "vqw_f16x3_split_activations: bad chunk range (kc0=%d KC=%d)", kc0, KC);
     const size_t n = (size_t)B * T * (C / 8);
-    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC);
+    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
+                       scale_dev, amax, flag);
     VQW_LAUNCH_CHECK("vqw_f16x3_split_activations");
     return 0;
 }
 
-int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count, vqw_stream_t s_) {
+int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count, const float* scale_dev, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(w && planes, "vqw_f16x3_pack_gate_weights: null pointer");
     VQW_CHECK(ks >= 1 && R > 0 && R % 128 == 0 && ldw >= 2 * R && count >= 1 && count <= 65535, "vqw_f16x3_pack_gate_weights: needs R %% 128 == 0, ldw >= 2R, 1 <= count <= 65535 (R=%d ldw=%d count=%d)", R, ldw, count);
     const int n = (ks * R / 8) * 2 * R;
-    hipLaunchKernelGGL(pack_gate_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale);
+    hipLaunchKernelGGL(pack_gate_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_gate_weights");
     return 0;
 }
 
-int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count, vqw_stream_t s_) {
+int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count, const float* scale_dev, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(w && planes, "vqw_f16x3_pack_weights: null pointer");
     VQW_CHECK(K > 0 && K % 8 == 0 && M > 0 && ldw >= M && count >= 1 && count <= 65535, "vqw_f16x3_pack_weights: needs K %% 8 == 0, ldw >= M, 1 <= count <= 65535 (K=%d M=%d ldw=%d count=%d)", K, M, ldw, count);
     const int n = (K / 8) * M;
-    hipLaunchKernelGGL(pack_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale);
+    hipLaunchKernelGGL(pack_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_weights");
     return 0;
 }

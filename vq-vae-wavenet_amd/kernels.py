@@ -201,30 +201,60 @@ def _need_planes(t, n_halves, what):
     L.require_cuda(t)
 
 
-def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0):
-    """scale * x [B][C][T] fp32 -> planes [2][KC or C/8][B*T][8] fp16, chunks kc0..."""
+def _slot(t, what, dtype=torch.float32):
+    """Device scalar (a 1-element view of the guard state) or None."""
+    if t is None:
+        return None
+    if t.dtype != dtype or t.numel() < 1 or not t.is_cuda:
+        raise ValueError('%s must be a %s device scalar' % (what, dtype))
+    return t.data_ptr()
+
+
+def f16x3_amax(x, amax, *, rows=None, cols=None, ld=None, mstride=0, count=1, flag=None):
+    """amax[i] (int32 holding the bits of a non-negative float) = max(amax[i], max |x_i|), `count` strided matrices."""
+    if rows is None:
+        rows, cols, ld = 1, x.numel(), x.numel()
+    _need(x, (count - 1) * mstride + (rows - 1) * ld + cols, 'x')
+    if amax.dtype != torch.int32 or amax.numel() < count:
+        raise ValueError('amax must be int32 [count]')
+    L.require_cuda(x, amax)
+    L.check(L.lib().vqw_f16x3_amax(L.ptr(x), rows, cols, ld, mstride, count, L.ptr(amax), _slot(flag, 'flag', torch.int32), L.stream()))
+
+
+def f16x3_update_scales(amax, scale, *, target_exp, reset=True, flag=None):
+    n = amax.numel()
+    if amax.dtype != torch.int32 or scale.dtype != torch.float32 or scale.numel() != n:
+        raise ValueError('amax int32 [n], scale float32 [n]')
+    L.require_cuda(amax, scale)
+    L.check(L.lib().vqw_f16x3_update_scales(L.ptr(amax), L.ptr(scale), n, target_exp, int(reset), _slot(flag, 'flag', torch.int32), L.stream()))
+
+
+def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_dev=None, amax=None, flag=None):
+    """scale * scale_dev * x [B][C][T] fp32 -> planes [2][KC or C/8][B*T][8] fp16, chunks kc0..."""
     _need(x, B * Cc * T, 'x')
     _need_planes(planes, 2 * B * T * (KC * 8 if KC else Cc), 'planes')
-    L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, float(scale), kc0, KC, L.stream()))
+    L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, float(scale), kc0, KC, _slot(scale_dev, 'scale_dev'),
+                                                _slot(amax, 'amax', torch.int32), _slot(flag, 'flag', torch.int32), L.stream()))
 
 
-def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1):
+def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1, scale_dev=None):
     """`count` layers back to back in `w` ([count][ks][R][ldw]) and in `planes`."""
     _need(w, (count - 1) * ks * R * ldw + (ks * R - 1) * ldw + 2 * R, 'w')
     _need_planes(planes, count * 2 * ks * R * 2 * R, 'planes')
-    L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), count, L.stream()))
+    L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), L.stream()))
 
 
-def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1):
-    """w [count][K][ldw] fp32 -> planes [count][2][K/8][M][8] fp16 of scale * w."""
+def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None):
+    """w [count][K][ldw] fp32 -> planes [count][2][K/8][M][8] fp16 of scale * scale_dev * w."""
     _need(w, (count - 1) * Kd * ldw + (Kd - 1) * ldw + M, 'w')
     _need_planes(planes, count * 2 * Kd * M, 'planes')
-    L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, L.stream()))
+    L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), L.stream()))
 
 
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
                    net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
-                   planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None):
+                   planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None, x_scale=None, w_scale=None,
+                   out_scale=None, out_amax=None, flag=None):
     cin = Cin if Cin > 0 else R
     kc_all = xp_KC if xp_KC > 0 else cin // 8
     _need_planes(xp, 2 * kc_all * 8 * B * T, 'xp')
@@ -256,11 +286,14 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     d.aux0 = None if aux0 is None else aux0.data_ptr()
     d.aux1 = None if aux1 is None else aux1.data_ptr()
     d.w_scale_inv = float(w_scale_inv)
+    d.x_scale, d.w_scale, d.out_scale = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale'), _slot(out_scale, 'out_scale')
+    d.out_amax, d.flag = _slot(out_amax, 'out_amax', torch.int32), _slot(flag, 'flag', torch.int32)
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 
 
 def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,
-                    cond_bstride=0, save0=None, save1=None, out_planes=None, out_planes_kc0=0, out_planes_KC=0):
+                    cond_bstride=0, save0=None, save1=None, out_planes=None, out_planes_kc0=0, out_planes_KC=0, x_scale=None,
+                    w_scale=None):
     _need_planes(xp, 2 * B * R * T, 'xp')
     _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
     _need(out0, B * R * T, 'out0')
@@ -287,6 +320,7 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     d.cond_bstride = cond_bstride
     d.B, d.T, d.R, d.ks, d.dilation, d.cond_T = B, T, R, ks, dilation, cond_T
     d.w_scale_inv = float(w_scale_inv)
+    d.x_scale, d.w_scale = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale')
     L.check(L.lib().vqw_f16x3_gate_conv(C.byref(d), L.stream()))
 
 

@@ -21,6 +21,7 @@ from . import kernels as K
 from .encoders import Encoder2019, EncoderMagenta
 
 BN_EPS = 1e-3  # Keras BatchNormalization default epsilon
+DEFAULT_ENGINE = 'fp32'
 
 
 def load_configs(model_json='model_parameters.json', wavenet_json=None):
@@ -83,16 +84,27 @@ class VQVAE:
         self.global_step = 0
         self.grad_sync = None   # parallel.GradAllReduce when training data-parallel
         self.overlap_wgrad = os.environ.get('VQW_OVERLAP', '1') != '0'   # decoder backward on two streams
-        # experimental: the decoder's gate convs on the fp16 matrix pipe with two-plane operands
-        # '1': gate convs; '2': gate convs + the 1x1 skip/residual convs (which then hand over the next layer's planes)
-        # '3': as '2', but the skip path of all layers as ONE contraction over the gated planes kept side by side
-        self.gate_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('1', '2', '3', '4', '5')
-        self.out_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('2', '3', '4', '5')
-        # '4': as '3', and the gate convs' input gradient (backward) with the gradient operand lifted by 2^20
-        self.skip_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('3', '4', '5')
-        # '5': as '4', and gate backward (dskip split once per step, dnet / dpre handed over as lifted planes)
-        self.dgrad_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') in ('4', '5')
-        self.gbwd_f16x3 = os.environ.get('VQW_GATE_F16X3', '0') == '5'
+        # Engine of the decoder's contractions.  VQW_ENGINE=f16x3: fp32 operands as two fp16 planes, three
+        # MFMA terms on the fp16 matrix pipe, fp32 accumulate, with device-side range guards (per-tensor power-of-two
+        # scales from measured max-abs values; a step whose planes would leave fp16's range is repeated on the fp32
+        # engine).  VQW_ENGINE=fp32: the fp32-MFMA engine everywhere.  VQW_GATE_F16X3=1..5 (development ladder, fixed
+        # scales, no guards): 1 gate convs; 2 + the 1x1 skip/residual convs; 3 skip path as ONE contraction; 4 + the gate
+        # convs' input gradient; 5 + gate backward.
+        engine = os.environ.get('VQW_ENGINE', DEFAULT_ENGINE)
+        if engine not in ('fp32', 'f16x3'):
+            raise ValueError("VQW_ENGINE must be 'fp32' or 'f16x3' (got %r)" % engine)
+        ladder = os.environ.get('VQW_GATE_F16X3', '0')
+        self.x3_guard = engine == 'f16x3' and ladder == '0'
+        if self.x3_guard:
+            ladder = '5'
+        self.gate_f16x3 = ladder in ('1', '2', '3', '4', '5')
+        self.out_f16x3 = ladder in ('2', '3', '4', '5')
+        self.skip_f16x3 = ladder in ('3', '4', '5')
+        self.dgrad_f16x3 = ladder in ('4', '5')
+        self.gbwd_f16x3 = ladder == '5'
+        self._x3_active = True         # False while a step is being repeated on the fp32 engine
+        self.x3_fallbacks = 0          # steps repeated on the fp32 engine because a plane left fp16's range
+        self.x3_steps = 0              # steps that ran on the fp16x3 engine
         self._side = None
         self._build_layout()
         self._init_params(seed)
@@ -102,6 +114,16 @@ class VQVAE:
         # tools/bench_kernels.py on MI355X at B=8, T=6656: block counts are 13*2^k, so the tile
         # that balances best over 256 CUs differs per GEMM shape
         self.tiles = {'out': 12, 'gate_bwd': 12, 'dgrad': 12}
+        # guard state of the fp16x3 engine: one power-of-two scale + one max-abs collector per tensor kind
+        #   WG all gate kernels | WO all 1x1 skip/residual kernels | G = dskip and every dnet (they share one contraction)
+        #   X[l] input planes of layer l (l = 0..L) | DP[l] d pre-activation of layer l
+        L = self.L
+        self.SL = {'WG': 0, 'WO': 1, 'G': 2, 'X': 3, 'DP': 3 + L + 1, 'N': 3 + 2 * L + 1}
+        self.x3_scale = torch.ones(self.SL['N'], device=self.dev)
+        self.x3_scale[self.SL['G']] = 2.0 ** 20          # first step: |d loss / d logits| <= 1 / (B T)
+        self.x3_scale[self.SL['DP']:] = 2.0 ** 20
+        self.x3_amax = torch.zeros(self.SL['N'], dtype=torch.int32, device=self.dev)
+        self.x3_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
     # ------------------------------------------------------------------ parameter layout
     def _build_layout(self):
@@ -424,26 +446,43 @@ class VQVAE:
         f16x3 = self.gate_f16x3 and T % 256 == 0 and R % 128 == 0 and (T // Tz) % 32 == 0
         f16x3_skip = f16x3 and self.skip_f16x3 and R % 256 == 0 and S % 256 == 0 and 2 * L * R * B * T * 2 < (1 << 31)
         f16x3_out = f16x3 and self.out_f16x3 and R % 256 == 0 and S % 256 == 0    # the 1x1 skip + residual conv too; it hands the next layer its planes
+        if self.x3_guard and not (f16x3_skip and self._x3_active):   # guarded engine: all of it or none of it
+            f16x3 = f16x3_skip = f16x3_out = False
+        ws['x3_used'] = bool(f16x3_skip and self.x3_guard)
+        gd = self.x3_guard and f16x3_skip
+        sc = (lambda name, i=0: self.x3_scale[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
+        am = (lambda name, i=0: self.x3_amax[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
+        flag = self.x3_flag if gd else None
+        WS = 1.0 if gd else 256.0          # guarded: the weight scale lives on the device (exact max-abs of this step's weights)
+        if gd:
+            K.f16x3_amax(P['gated_w'], am('WG'), flag=flag)
+            K.f16x3_amax(P['out_w'], am('WO'), flag=flag)
+            K.f16x3_amax(net[0], am('X', 0), flag=flag)
+            # weights and the first layer's input: exact scales (amax < 2^14 after scaling); the collectors restart
+            K.f16x3_update_scales(self.x3_amax[:2], self.x3_scale[:2], target_exp=14, flag=flag)
+            K.f16x3_update_scales(am('X', 0), sc('X', 0), target_exp=13, flag=flag)
         if f16x3:      # this step's weights of all layers as fp16 planes, one launch per kind
-            K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, 256.0, count=L)
+            K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, WS, count=L, scale_dev=sc('WG'))
             if f16x3_skip:     # [L*R][S] skip kernels of all layers as one K = L*R operand; the residual kernels per layer
-                K.f16x3_pack_weights(P['out_w'], ws['wskip'], L * R, S, S + R, 256.0)
-                K.f16x3_pack_weights(P['out_w'].view(-1)[S:], ws['wres'], R, R, S + R, 256.0, count=L)
+                K.f16x3_pack_weights(P['out_w'], ws['wskip'], L * R, S, S + R, WS, scale_dev=sc('WO'))
+                K.f16x3_pack_weights(P['out_w'].view(-1)[S:], ws['wres'], R, R, S + R, WS, count=L, scale_dev=sc('WO'))
             elif f16x3_out:
-                K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, 256.0, count=L)
+                K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, WS, count=L)
         for l, d in enumerate(self.dil):
             if f16x3:
                 if l == 0 or not f16x3_out:
-                    K.f16x3_split_activations(net[l], ws['xp'], B, R, T)
+                    K.f16x3_split_activations(net[l], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag)
                 K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if save else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
                                   cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T=T, R=R, ks=self.ks,
-                                  dilation=d, w_scale_inv=1.0 / 256.0, out_planes=ws['gp'] if f16x3_out else None,
-                                  out_planes_kc0=l * (R // 8) if f16x3_skip else 0, out_planes_KC=L * (R // 8) if f16x3_skip else 0)
+                                  dilation=d, w_scale_inv=1.0 / WS, out_planes=ws['gp'] if f16x3_out else None,
+                                  out_planes_kc0=l * (R // 8) if f16x3_skip else 0, out_planes_KC=L * (R // 8) if f16x3_skip else 0,
+                                  x_scale=sc('X', l), w_scale=sc('WG'))
                 if f16x3_skip:   # residual half now; the skip half of all layers after the loop
                     K.f16x3_out_conv(xp=ws['gp'], xp_kc0=l * (R // 8), xp_KC=L * (R // 8), Cin=R, wp=ws['wres'][l],
                                      bias=P['out_b'][l][S:], net_in=net[l], net_out=net[l + 1], net_out_planes=ws['xp'],
-                                     B=B, T=T, R=R, S=0, w_scale_inv=1.0 / 256.0)
+                                     B=B, T=T, R=R, S=0, w_scale_inv=1.0 / WS, w_scale=sc('WO'), out_scale=sc('X', l + 1),
+                                     out_amax=am('X', l + 1), flag=flag)
                 elif f16x3_out:
                     K.f16x3_out_conv(xp=ws['gp'], wp=ws['wop'][l], bias=P['out_b'][l], skip=ws['skip'], net_in=net[l],
                                      net_out=net[l + 1], net_out_planes=ws['xp'], B=B, T=T, R=R, S=S, w_scale_inv=1.0 / 256.0)
@@ -462,7 +501,7 @@ class VQVAE:
                         epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])                                       # :132-136, wavenet.py:72-73
         if f16x3_skip:   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
             K.f16x3_out_conv(xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
-                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / 256.0)
+                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / WS, w_scale=sc('WO'))
         K.conv_gemm(x0=ws['skip'], in_relu=True, w=P['post1_w'], bias=P['post1_b'], out0=ws['h1'],
                     cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T, M=S,
                     C0=S, taps=[0])                                                       # wavenet.py:80-88
@@ -548,14 +587,25 @@ class VQVAE:
         # Experimental: the gate convs' input gradient on the fp16 matrix pipe.  d(loss)/d(logits) is bounded by 1 / (B T), the
         # gradient operand is lifted by 2^20 before it is split into fp16 planes (|dpre| < 0.06 assumed, not checked).
         dgrad_x3 = self.dgrad_f16x3 and T % 256 == 0 and R % 256 == 0
-        GS = float(2 ** 20)
         gbwd_x3 = dgrad_x3 and self.gbwd_f16x3 and S % 256 == 0
+        gd = bool(ws.get('x3_used'))
+        if self.x3_guard and not gd:
+            dgrad_x3 = gbwd_x3 = False
+        calib = self.x3_guard and not self._x3_active     # fp32 repeat of a step: measure what the planes would have held
+        sc = (lambda name, i=0: self.x3_scale[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
+        am = (lambda name, i=0: self.x3_amax[self.SL[name] + i:self.SL[name] + i + 1]) if (gd or calib) else (lambda name, i=0: None)
+        flag = self.x3_flag if gd else None
+        GS = 1.0 if gd else float(2 ** 20)      # guarded: the gradient scales live on the device
+        WS = 1.0 if gd else 256.0
         if dgrad_x3:
-            K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, 256.0, count=L)
+            K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, WS, count=L, scale_dev=sc('WG'))
         if gbwd_x3:
-            K.f16x3_pack_weights(Tt['out_w'], ws['wgb'], S + R, R, R, 256.0, count=L)
-            K.f16x3_pack_weights(Tt['out_w'][L - 1], ws['wgb_top'], S, R, R, 256.0)       # the top layer has no dnet
-            K.f16x3_split_activations(dskip, ws['gr'], B, S, T, scale=GS, kc0=0, KC=(S + R) // 8)   # one tensor for all layers
+            K.f16x3_pack_weights(Tt['out_w'], ws['wgb'], S + R, R, R, WS, count=L, scale_dev=sc('WO'))
+            K.f16x3_pack_weights(Tt['out_w'][L - 1], ws['wgb_top'], S, R, R, WS, scale_dev=sc('WO'))       # the top layer has no dnet
+            K.f16x3_split_activations(dskip, ws['gr'], B, S, T, scale=GS, kc0=0, KC=(S + R) // 8, scale_dev=sc('G'),
+                                      amax=am('G'), flag=flag)   # one tensor for all layers
+        if calib:
+            K.f16x3_amax(dskip, am('G'))
         side_done = {}
         dnet = dnet_ring[(L - 1) % 3]
         for l in range(L - 1, -1, -1):
@@ -568,11 +618,14 @@ class VQVAE:
             if gbwd_x3:
                 K.f16x3_out_conv(epi=1, xp=ws['gr'], Cin=S if top else S + R, xp_KC=(S + R) // 8,
                                  wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=ws['th'][l], aux1=ws['sg'][l], net_out=dpre,
-                                 net_out_planes=ws['dp'], plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (256.0 * GS))
+                                 net_out_planes=ws['dp'], plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (WS * GS),
+                                 x_scale=sc('G'), w_scale=sc('WO'), out_scale=sc('DP', l), out_amax=am('DP', l), flag=flag)
             else:
                 K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
                             aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
                             epilogue=K.EPI_GATE_BWD, tile=self.tiles['gate_bwd'])
+            if calib:
+                K.f16x3_amax(dpre, am('DP', l))
             if side is not main:
                 ready = torch.cuda.Event()
                 ready.record(main)
@@ -582,15 +635,18 @@ class VQVAE:
                     K.f16x3_split_activations(dpre, ws['dp'], B, 2 * R, T, scale=GS)
                 K.f16x3_out_conv(xp=ws['dp'], Cin=2 * R, ks=ks, dilation=d, direction=-1, wp=ws['wdg'][l],
                                  net_in=None if top else dnet, net_out=dnet_next, B=B, T=T, R=R, S=0,
-                                 w_scale_inv=1.0 / (256.0 * GS),
+                                 w_scale_inv=1.0 / (WS * GS),
                                  net_out_planes=ws['gr'] if gbwd_x3 else None, planes_kc0=S // 8 if gbwd_x3 else 0,
-                                 planes_KC=(S + R) // 8 if gbwd_x3 else 0, plane_scale=GS if gbwd_x3 else 0.0)
+                                 planes_KC=(S + R) // 8 if gbwd_x3 else 0, plane_scale=GS if gbwd_x3 else 0.0,
+                                 x_scale=sc('DP', l), w_scale=sc('WG'), out_scale=sc('G'), out_amax=am('G'), flag=flag)
             elif top:
                 K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
                             tile=self.tiles['dgrad'])
             else:
                 K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out1=dnet_next, aux1=dnet, out0=dnet_next, B=B, T_in=T, T_out=T,
                             M=R, M0=0, C0=2 * R, taps=taps_b, epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['dgrad'])
+            if calib:
+                K.f16x3_amax(dnet_next, am('G'))
             with torch.cuda.stream(side):
                 if side is not main:
                     side.wait_event(ready)
@@ -702,12 +758,43 @@ class VQVAE:
 
     def train_step(self, x, spk):
         """One sess.run(train_op) (train.py:104-114).  With self.grad_sync set (data parallel)
-        the flat gradient is sum-all-reduced over RCCL in two overlapped buckets and averaged."""
+        the flat gradient is sum-all-reduced over RCCL in two overlapped buckets and averaged.
+        Guarded fp16x3 engine: the step's range flag is read before the optimiser runs (one host sync per step); a
+        step whose planes left fp16's range is repeated on the fp32 engine, which also measures the max-abs values the
+        next step's scales come from."""
+        if self.x3_guard:
+            self.x3_flag.zero_()
         ws = self.forward(x, spk)
         self.backward(x, spk, ws)
         world = self.grad_sync.finish() if self.grad_sync is not None else 1
+        if self.x3_guard and ws.get('x3_used'):
+            if self._x3_overflowed():
+                self.x3_fallbacks += 1
+                self._x3_active = False
+                try:
+                    self.x3_amax.zero_()
+                    ws = self.forward(x, spk)
+                    for l in range(1, self.L):       # what the layer-input planes would have held
+                        K.f16x3_amax(ws['net'][l], self.x3_amax[self.SL['X'] + l:self.SL['X'] + l + 1])
+                    self.backward(x, spk, ws)
+                    world = self.grad_sync.finish() if self.grad_sync is not None else 1
+                finally:
+                    self._x3_active = True
+            else:
+                self.x3_steps += 1
+            # next step's scales of the planes written inside the kernels (max-abs * scale in [2^12, 2^13): 8x headroom)
+            n0 = self.SL['G']
+            K.f16x3_update_scales(self.x3_amax[n0:], self.x3_scale[n0:], target_exp=13)
         self.apply_gradients(1.0 / world)
         return ws
+
+    def _x3_overflowed(self):
+        """Range flag of this step (max over the data-parallel ranks: every rank must take the same branch)."""
+        flag = self.x3_flag
+        if self.grad_sync is not None and self.grad_sync.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.grad_sync.group)
+        return int(flag.item()) != 0
 
     # ------------------------------------------------------------------ generation
     def encode(self, x, spk):
