@@ -774,7 +774,7 @@ class VQVAE:
                 try:
                     self.x3_amax.zero_()
                     ws = self.forward(x, spk)
-                    for l in range(1, self.L):       # what the layer-input planes would have held
+                    for l in range(1, self.L + 1):   # what the layer-input planes would have held
                         K.f16x3_amax(ws['net'][l], self.x3_amax[self.SL['X'] + l:self.SL['X'] + l + 1])
                     self.backward(x, spk, ws)
                     world = self.grad_sync.finish() if self.grad_sync is not None else 1
