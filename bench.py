@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 matrix peak, same guide (only used by the experimental VQW_GATE_F16X3=1 mode)
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 matrix peak, same guide (the fp16x3 engine's pipe)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -68,7 +68,7 @@ class GateConvTimer:
         self.K = kernels_mod
         self.orig = kernels_mod.conv_gemm
         self.orig_x3 = kernels_mod.f16x3_gate_conv
-        self.x3 = False          # the experimental fp16x3 gate kernel was the one launched
+        self.x3 = False          # the fp16x3 gate kernel was the one launched
         self.events = []
         self.on = False
 
@@ -108,10 +108,10 @@ class GateConvTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
 
 
-def hbm_traffic():
+def hbm_traffic(name='round1_gate_conv_traffic.json'):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/round1_gate_conv_traffic.json, made by tools/pmc_traffic.py); None if absent."""
-    p = os.path.join(ROOT, 'profiles', 'round1_gate_conv_traffic.json')
+    (profiles/<name>, made by tools/pmc_traffic.py); None if absent."""
+    p = os.path.join(ROOT, 'profiles', name)
     if not os.path.exists(p):
         return None
     with open(p) as fh:
@@ -201,7 +201,7 @@ def main():
                     "'2019' needs --length 6400 (T %% 320 == 0): BASELINE.json configs[4] in fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
-    ap.add_argument('--no-experimental', action='store_true', help='skip the extra timing of the opt-in fp16x3 forward path')
+    ap.add_argument('--no-other-engine', action='store_true', help='skip the extra timing of the same step on the fp32-MFMA engine')
     ap.add_argument('--probe-ranks', action='store_true', help='only start the ranks and report how many joined (no GPU work)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 code path)")
     a = ap.parse_args()
@@ -283,15 +283,15 @@ def main():
     loss = model.losses(ws)[0]
     log('train: %.2f ms/step, loss %.5f' % (dt / a.steps * 1e3, loss))
 
-    # Reported beside the headline, never as it: the same step with the opt-in fp16x3 forward convs
+    # Beside the headline: the same step on the other engine (VQW_ENGINE=fp32: the fp32-MFMA engine everywhere)
     exp = None
-    if world == 1 and not a.no_experimental and os.environ.get('VQW_GATE_F16X3', '0') == '0':
+    if world == 1 and not a.no_other_engine and model.x3_guard:
         try:
-            os.environ['VQW_GATE_F16X3'] = '5'
+            os.environ['VQW_ENGINE'] = 'fp32'
             try:
                 model_x = pkg.model.VQVAE(m, w, S, device=dev, seed=0)
             finally:
-                os.environ['VQW_GATE_F16X3'] = '0'
+                del os.environ['VQW_ENGINE']
             for _ in range(a.warmup):
                 model_x.train_step(x, spk)
             torch.cuda.synchronize()
@@ -300,17 +300,15 @@ def main():
                 ws_x = model_x.train_step(x, spk)
             torch.cuda.synchronize()
             dtx = time.perf_counter() - tx
-            exp = {"switch": "VQW_GATE_F16X3=5", "what": "decoder forward gate / residual / skip convs as fp32-accurate 3-term contractions "
-                   "of two-plane fp16 operands on the fp16 matrix pipe (parity tests at the fp32 path's tolerances), and gate backward + the gate convs' input gradient likewise with the gradient operands lifted by 2^20; weight gradients and the encoder unchanged",
+            exp = {"switch": "VQW_ENGINE=fp32", "what": "every contraction of the step on the fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                    "value": B * T * a.steps / dtx, "unit": "audio-samples/s", "ms_per_step": dtx / a.steps * 1e3,
                    "loss": model_x.losses(ws_x)[0]}
-            log('experimental fp16x3 forward: %.2f ms/step, loss %.5f' % (exp["ms_per_step"], exp["loss"]))
+            log('fp32 engine: %.2f ms/step, loss %.5f' % (exp["ms_per_step"], exp["loss"]))
             del model_x, ws_x
             torch.cuda.empty_cache()
-        except Exception as e:   # the headline must not depend on the opt-in path
-            os.environ['VQW_GATE_F16X3'] = '0'
-            exp = {"switch": "VQW_GATE_F16X3=5", "error": '%s: %s' % (type(e).__name__, e)}
-            log('experimental fp16x3 leg failed: %s' % exp['error'])
+        except Exception as e:   # the headline must not depend on the comparison leg
+            exp = {"switch": "VQW_ENGINE=fp32", "error": '%s: %s' % (type(e).__name__, e)}
+            log('fp32-engine leg failed: %s' % exp['error'])
 
     gen = None
     if not a.no_gen:
@@ -366,13 +364,19 @@ def main():
                          "ms_per_launch": gate_ms, "flop_per_launch": flops_gate,
                          "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
         }
-        if gate_x3:   # VQW_GATE_F16X3=1 (experimental): three fp16 MFMA terms per product, priced on the 16-bit pipe
-            rec["dtype"] = "f32 (gate convs: fp32 operands as two fp16 planes, 3 MFMA terms, fp32 accumulate)"
-            rec["roofline"].update({"kernel": "gate_f16x3_kernel (experimental; dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate on the fp16 matrix pipe)",
+        if gate_x3:   # the fp16x3 engine ran: three fp16 MFMA terms per product, priced on the 16-bit pipe
+            rec["dtype"] = ("f32 (storage and accumulation fp32; decoder contractions: each fp32 operand as two fp16 planes = 22 "
+                            "significand bits, products h1h1 + h1h2 + h2h1 on the fp16 MFMA, device-side range guards; "
+                            "encoder, head and weight gradients on the fp32 MFMA)")
+            rec["config"]["workload"] = rec["config"]["workload"].replace("fp32,", "fp32 (fp16x3 engine),")
+            rec["roofline"].update({"kernel": "gate_f16x3_kernel (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; operands as two fp16 planes, 3 MFMA terms)",
                                     "achieved": 3 * ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * ach / PEAK_F16_MFMA_TFLOPS,
-                                    "fp32_equivalent_tflops": ach, "flop_per_launch": 3 * flops_gate, "traffic": None})
+                                    "fp32_equivalent_tflops": ach, "flop_per_launch": 3 * flops_gate, "traffic": hbm_traffic('round2_gate_f16x3_traffic.json'),
+                                    "whole_step_frac": None,
+                                    "whole_step_fp32_equivalent_tflops": 118.14e6 * B * T * a.steps / dt / 1e12})
+            rec["engine"] = {"name": "f16x3", "steps_on_engine": model.x3_steps, "steps_repeated_on_fp32": model.x3_fallbacks}
         if exp:
-            rec["experimental_f16x3"] = exp
+            rec["engine_fp32"] = exp
         if gen:
             rec["ar_gen"] = gen
         if world == 1 and not a.no_cpu_baseline:

@@ -40,16 +40,37 @@ def relerr(a, b):
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
 
 
-def test_bench_workload_full_step_matches_oracle(pkg):
-    bench = _bench()
-    m, w = bench.default_configs()
-    B, T, S = 8, 6656, 109
-    model = pkg.model.VQVAE(m, w, S, device='cuda', seed=0)              # bench.py's weights
-    x, spk = bench.synthetic_batch(B, T, S, 1234, 'cuda')                # bench.py's rank-0 batch
-    P = {k: v.cpu() for k, v in model.named_parameters().items()}
-    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
-    st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
-    out, grads = M.train_step(x.cpu().unsqueeze(-1), spk.cpu(), P, m, w, st, 0)
+_ORACLE = {}
+
+
+def _oracle_step(pkg):
+    """The oracle's step on bench.py's problem, computed once for both engines (~25 s of host time)."""
+    if not _ORACLE:
+        bench = _bench()
+        m, w = bench.default_configs()
+        B, T, S = 8, 6656, 109
+        model = pkg.model.VQVAE(m, w, S, device='cuda', seed=0)              # bench.py's weights
+        x, spk = bench.synthetic_batch(B, T, S, 1234, 'cuda')                # bench.py's rank-0 batch
+        P0 = {k: v.cpu() for k, v in model.named_parameters().items()}
+        P = {k: v.clone() for k, v in P0.items()}
+        del model
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+        st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
+        out, grads = M.train_step(x.cpu().unsqueeze(-1), spk.cpu(), P, m, w, st, 0)
+        keep = ('q', 'labels', 'z_e', 'logits', 'reconstruction_loss', 'vq_loss', 'loss')
+        _ORACLE.update(m=m, w=w, x=x, spk=spk, P0=P0, P=P, grads=grads, out={k: out[k].detach() for k in keep})
+    return _ORACLE
+
+
+@pytest.mark.parametrize('engine', ['f16x3', 'fp32'])
+def test_bench_workload_full_step_matches_oracle(pkg, monkeypatch, engine):
+    """engine: the default (fp16x3 with range guards: what bench.py times) and the fp32-MFMA engine (VQW_ENGINE=fp32)."""
+    monkeypatch.setenv('VQW_ENGINE', engine)
+    o = _oracle_step(pkg)
+    m, w, x, spk, P, grads, out = o['m'], o['w'], o['x'], o['spk'], o['P'], o['grads'], o['out']
+    model = pkg.model.VQVAE(m, w, 109, device='cuda', seed=0)
+    model.load_named(o['P0'])
+    assert model.x3_guard == (engine == 'f16x3')
     ws = model.forward(x, spk, compute_grad_seed=False)
     assert torch.equal(ws['idx'].cpu(), out['q']), 'VQ indices differ'
     assert torch.equal(ws['labels'].cpu().reshape(-1), out['labels']), 'mu-law labels differ'
@@ -58,6 +79,7 @@ def test_bench_workload_full_step_matches_oracle(pkg):
     assert relerr(logits, out['logits']) < 5e-4
     del logits
     ws = model.train_step(x, spk)
+    assert bool(ws['x3_used']) == (engine == 'f16x3') and model.x3_fallbacks == 0
     loss, recon, vq, commit = model.losses(ws)
     np.testing.assert_allclose(recon, out['reconstruction_loss'].item(), rtol=2e-5)
     np.testing.assert_allclose(vq, out['vq_loss'].item(), rtol=2e-5)
@@ -81,7 +103,9 @@ def test_bench_workload_full_step_matches_oracle(pkg):
         firm = gref.abs() > 1e-5
         if firm.any():
             assert float(diff[firm].max()) <= 1e-2 * lr, 'param %s after the step: %.3e' % (name, float(diff[firm].max()))
-    print('bench-shape step: loss %.6f (oracle %.6f), worst grad %s %.2e' % (loss, out['loss'].item(), *worst))
+    print('bench-shape step (%s): loss %.6f (oracle %.6f), worst grad %s %.2e' % (engine, loss, out['loss'].item(), *worst))
+    del model
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('persistent', ['1', '0'])

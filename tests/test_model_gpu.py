@@ -185,6 +185,9 @@ def test_guarded_f16x3_engine_three_steps(pkg, monkeypatch):
     xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
     st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
     for step in range(3):
+        # every step starts from the oracle's parameters (two fp32 evaluations part ways after one Adam step: the sign of a
+        # gradient at rounding level decides the direction of that parameter's first move); the guard state carries over
+        model.load_named(P, also_ema=False)
         out, grads = M.train_step(x, spk, P, m, w, st, step)
         ws = model.train_step(xd, sd)
         assert ws['x3_used']
@@ -233,6 +236,7 @@ def test_guarded_f16x3_engine_adversarial_ranges(pkg, monkeypatch, what):
     st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
     used = []
     for step in range(3):
+        model.load_named(P, also_ema=False)          # as in test_guarded_f16x3_engine_three_steps
         out, grads = M.train_step(x, spk, P, m, w, st, step)
         ws = model.train_step(xd, sd)
         used.append(bool(ws['x3_used']))

@@ -23,6 +23,13 @@ def main():
     if what == 'gradients':
         P['decoder/postprocess2/kernel'] *= 8.0
         P['decoder/postprocess1/kernel'] *= 8.0
+    if what == 'weights':
+        P['decoder/cycle_2/layer_3/gated/kernel'] *= 1e4
+    if what == 'activations':
+        P['decoder/preprocess/kernel'] *= 3e5
+        for name in P:
+            if name.endswith('/gated/kernel'):
+                P[name] *= 1e-5
     x, spk, _ = M.synthetic_batch(1, 1024, 109, 1234)
     xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
     models = {}
@@ -33,6 +40,8 @@ def main():
         models[eng] = mdl
     st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
     for step in range(3):
+        for mdl in models.values():          # every step starts from the oracle's parameters: the trajectories of two fp32
+            mdl.load_named(P, also_ema=False)  # evaluations part after one Adam step (sign of gradients at rounding level)
         out, grads = M.train_step(x, spk, P, m, w, st, step)
         res = {}
         for eng, mdl in models.items():
@@ -44,6 +53,10 @@ def main():
             print('   %-55s f16x3 %.2e  fp32 %.2e' % (n, e3, e32))
         import statistics
         print('   median ratio f16x3/fp32: %.2f' % statistics.median(e3 / max(e32, 1e-12) for e3, e32, _ in rows))
+        mx = models['f16x3']
+        sc = mx.x3_scale.cpu()
+        print('   scales: WG %g WO %g G %g  X %s  DP %s' % (sc[0], sc[1], sc[2], ' '.join('%g' % v for v in sc[3:3 + mx.L + 1:5]),
+                                                        ' '.join('%g' % v for v in sc[3 + mx.L + 1::5])))
     print('fallbacks', models['f16x3'].x3_fallbacks, 'scales G %g' % float(models['f16x3'].x3_scale[2]))
 
 

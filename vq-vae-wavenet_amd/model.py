@@ -21,7 +21,7 @@ from . import kernels as K
 from .encoders import Encoder2019, EncoderMagenta
 
 BN_EPS = 1e-3  # Keras BatchNormalization default epsilon
-DEFAULT_ENGINE = 'fp32'
+DEFAULT_ENGINE = 'f16x3'
 
 
 def load_configs(model_json='model_parameters.json', wavenet_json=None):
