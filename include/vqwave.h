@@ -397,6 +397,31 @@ typedef struct vqw_f16x3_out_desc {
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 
+/* Weight gradient of conv1d_v2 (TF Conv2DBackpropFilter, wavenet_ops.py:83-86) on the fp16x3 engine:
+ *   dw[j][c][o] += sum_{b,t} p[b][c][t + tap_shift[j]] * q[b][o][t],   q = [q0 (Q0 rows); q1 (Q1 rows)] along o,
+ * p [B][Cp][T], q0 [B][Q0][T], q1 [B][Q1][T] fp32 (time contiguous = the contraction index: the operands are split into
+ * fp16 planes inside the kernel, with the power-of-two guard scales *_scale (device scalars or NULL) of the same tensors'
+ * planes, whose producers range-check them).  T % 32 == 0; Cp, Q0, Q1 multiples of 256; tap_shift <= 0 (reads outside
+ * [0, T) are zero).  `slab` is scratch: tiles * nsplit * 65536 floats (tiles = ntaps * Cp/256 * (Q0+Q1)/256; nsplit 0 =
+ * CUs / tiles): partial tiles are summed in a fixed order by a second launch -- dw is bitwise reproducible.          */
+typedef struct vqw_f16x3_wgrad_desc {
+    const float* p;
+    const float* q0;
+    const float* q1;        /* or NULL with Q1 = 0                                                          */
+    float* dw;              /* [ntaps][Cp][lddw] (tap stride dw_tap_stride), accumulated into               */
+    float* slab;
+    int64_t slab_floats;
+    const float* p_scale;
+    const float* q0_scale;
+    const float* q1_scale;
+    int32_t B, T, Cp, Q0, Q1, ntaps;
+    int32_t tap_shift[VQW_MAX_TAPS];
+    int32_t lddw;           /* 0 = Q0 + Q1                                                                  */
+    int32_t nsplit;         /* 0 = one round of blocks                                                      */
+    int64_t dw_tap_stride;  /* 0 = Cp * lddw                                                                */
+} vqw_f16x3_wgrad_desc;
+int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -482,6 +482,72 @@ def test_dgrad_f16x3_matches_fp32_engine(K, B, T, d, top):
     assert err <= 2e-5, 'input gradient differs from the fp32 engine by %.3e of max' % err
 
 
+@pytest.mark.parametrize('B,T,d,Q1,scaled', [(2, 512, 1, 256, False), (2, 512, 2, 0, True), (1, 1024, 4, 256, True), (2, 512, 16, 256, False),
+                                             (1, 512, 512, 0, False), (3, 544, 3, 256, True)])
+def test_wgrad_f16x3_matches_fp64(K, B, T, d, Q1, scaled):
+    """vqw_f16x3_wgrad (the weight gradient of a causal dilated conv with two gradient sources, on the fp16 pipe with
+    the operands split in registers) against an fp64 evaluation: taps that read before t = 0 (zero), shifts that are
+    not multiples of 4 (16-byte windows straddling the row start), a dilation beyond the signal, guard scales, a T
+    that is not a multiple of 64, accumulation into dw, run-to-run bitwise reproducibility."""
+    Cp, Q0, ks = 256, 512, 3
+    gen = torch.Generator().manual_seed(100 + d)
+    p = torch.randn(B, Cp, T, generator=gen).to(DEV)
+    q0 = (torch.randn(B, Q0, T, generator=gen) * (1e-6 if scaled else 1.0)).to(DEV)
+    q1 = (torch.randn(B, Q1, T, generator=gen) * (3e-6 if scaled else 1.0)).to(DEV) if Q1 else None
+    taps = [-(ks - 1 - j) * d for j in range(ks)]
+    sc = torch.tensor([4.0, 2.0 ** 30, 2.0 ** 28] if scaled else [1.0, 1.0, 1.0], device=DEV)
+    dw0 = torch.randn(ks, Cp, Q0 + Q1, generator=gen).to(DEV)
+    slab = torch.empty(64 * 65536 * 4, device=DEV)
+
+    def run():
+        dw = dw0.clone()
+        K.f16x3_wgrad(p=p, q0=q0, q1=q1, Q1=Q1, dw=dw, slab=slab, B=B, T=T, Cp=Cp, Q0=Q0, taps=taps,
+                      p_scale=sc[0:1], q0_scale=sc[1:2], q1_scale=sc[2:3] if Q1 else None)
+        return dw
+    got = run()
+    q = torch.cat([q0, q1], 1).double() if Q1 else q0.double()
+    want = dw0.double().clone()
+    for j, sh in enumerate(taps):
+        ps = torch.zeros(B, Cp, T, dtype=torch.float64, device=DEV)
+        if -sh < T:
+            ps[:, :, -sh:] = p.double()[:, :, :T + sh]
+        want[j] += torch.einsum('bct,bot->co', ps, q)
+    upd = (want - dw0.double()).abs().max().item()
+    err = (got.double() - want).abs().max().item()
+    assert err <= 2e-6 * max(upd, 1e-30) + 1e-6 * dw0.abs().max().item(), 'max err %.3e of update %.3e' % (err, upd)
+    assert torch.equal(run(), got), 'dw is not bitwise reproducible'
+
+
+def test_wgrad_f16x3_full_size_matches_fp32_engine(K):
+    """The benchmark's shapes (B=8, T=6656: 1664 stage pairs over 42 / 85 K splits): gate-conv and 1x1 weight gradients
+    against the fp32 engine's wgrad kernel and fp64 samples."""
+    B, T, R, S = 8, 6656, 256, 512
+    gen = torch.Generator().manual_seed(9)
+    net = torch.randn(B, R, T, generator=gen).to(DEV)
+    dpre = (torch.randn(B, 2 * R, T, generator=gen) * 1e-5).to(DEV)
+    dskip = (torch.randn(B, S, T, generator=gen) * 1e-5).to(DEV)
+    dnet = (torch.randn(B, R, T, generator=gen) * 3e-5).to(DEV)
+    slab = torch.empty(256 * 65536, device=DEV)
+    sc = torch.tensor([2.0 ** 10, 2.0 ** 27, 2.0 ** 26], device=DEV)
+    for d in (1, 64, 512):
+        taps = [-2 * d, -d, 0]
+        dw = torch.zeros(3, R, 2 * R, device=DEV)
+        K.f16x3_wgrad(p=net, q0=dpre, dw=dw, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, taps=taps, p_scale=sc[0:1], q0_scale=sc[1:2])
+        ref = torch.zeros_like(dw)
+        K.wgrad_gemm(p=net, q0=dpre, dw=ref, B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R, taps=taps)
+        close(dw, ref, rtol=2e-5, atol=2e-5, what='gate wgrad d=%d vs the fp32 engine' % d)
+        for (j, c, o) in ((0, 3, 500), (1, 255, 0), (2, 100, 257)):
+            sh = -taps[j]
+            w64 = (net[:, c, :T - sh].double() * dpre[:, o, sh:].double()).sum().item()
+            assert abs(dw[j, c, o].item() - w64) <= 2e-6 * dw.abs().max().item(), (d, j, c, o)
+    dw = torch.zeros(R, S + R, device=DEV)
+    K.f16x3_wgrad(p=net, q0=dskip, q1=dnet, Q1=R, dw=dw, slab=slab, B=B, T=T, Cp=R, Q0=S, taps=[0], p_scale=sc[0:1],
+                  q0_scale=sc[1:2], q1_scale=sc[2:3])
+    ref = torch.zeros_like(dw)
+    K.wgrad_gemm(p=net, q0=dskip, q1=dnet, dw=ref, B=B, T_q=T, T_p=T, Cp=R, Q0=S, Q1=R, lddw=S + R, taps=[0])
+    close(dw, ref, rtol=2e-5, atol=2e-5, what='1x1 wgrad vs the fp32 engine')
+
+
 def test_accum_split_and_two_sources(K):
     B, T, Cg, S, Rr = 2, 512, 32, 64, 32
     gated, w, b = rnd(B, T, Cg, seed=1), rnd(Cg, S + Rr, seed=2, s=0.2), rnd(S + Rr, seed=3)

@@ -75,6 +75,15 @@ class F16x3OutDesc(C.Structure):
         ('x_scale', _fp), ('w_scale', _fp), ('out_scale', _fp), ('out_amax', _fp), ('flag', _fp),
     ]
 
+class F16x3WgradDesc(C.Structure):
+    _fields_ = [
+        ('p', _fp), ('q0', _fp), ('q1', _fp), ('dw', _fp), ('slab', _fp), ('slab_floats', C.c_int64),
+        ('p_scale', _fp), ('q0_scale', _fp), ('q1_scale', _fp),
+        ('B', C.c_int32), ('T', C.c_int32), ('Cp', C.c_int32), ('Q0', C.c_int32), ('Q1', C.c_int32), ('ntaps', C.c_int32),
+        ('tap_shift', C.c_int32 * MAX_TAPS), ('lddw', C.c_int32), ('nsplit', C.c_int32), ('dw_tap_stride', C.c_int64),
+    ]
+
+
 _i, _f, _sz, _i64 = C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     'vqw_last_error': (C.c_char_p, []),
@@ -123,6 +132,7 @@ SIGNATURES = {
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),
     'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _fp]),
     'vqw_f16x3_out_conv': (_i, [C.POINTER(F16x3OutDesc), _fp]),
+    'vqw_f16x3_wgrad': (_i, [C.POINTER(F16x3WgradDesc), _fp]),
 }
 
 _lib = None

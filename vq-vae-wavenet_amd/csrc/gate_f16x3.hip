@@ -17,6 +17,8 @@
 // lane) x 256 time steps; four waves, each all 256 channels x 64 time steps (16 accumulator tiles in AGPRs); K step = 16
 // input channels of one tap; operands through VGPRs into a 4-stage LDS ring, MFMA fragments double-buffered in
 // registers (read from LDS one step ahead), one barrier per step.
+#include <string.h>
+
 #include "vqw_common.h"
 
 namespace {
@@ -493,6 +495,182 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a)
     if (d.net_out_planes) guard_report(gmax, gbad, ps, d.out_amax, d.flag);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients on the fp16 matrix pipe:  dW[j][c][o] += sum_{b,t} p[b][c][t + shift_j] * q[b][o][t]
+// (TF Conv2DBackpropFilter of conv1d_v2, wavenet_ops.py:83-86; q = [q0; q1] along o).
+//
+// The contraction index is TIME, which is the contiguous index of both fp32 operands [B][C][T]: an MFMA fragment entry
+// (row, 8 consecutive k) is 32 contiguous bytes of global memory.  The operands are therefore read as fp32 (whole
+// 128-byte lines per row and 32-step stage pair), scaled by their power-of-two guard scale, split into the two fp16
+// planes IN REGISTERS (same bytes as reading ready-made planes, no conversion pass, no plane copy in HBM) and written
+// to the same LDS stage image as the kernels above, so the fragment reads and the 3-term MFMA loop are shared.
+// Output tile 256 (c) x 256 (o) per block; the K range B*T is cut into `nsplit` contiguous chunks per tile so that
+// tiles * nsplit fills the chip once; partial tiles go to a slab [tile][split][256][256] and a second kernel adds them
+// up in a fixed order (no atomics: dW is bitwise reproducible).  Needs T % 32 == 0, C % 256 == 0, shifts <= 0.
+struct WgArgs {
+    const float* p;
+    const float* q0;
+    const float* q1;
+    float* slab;
+    const float* sp;      // device scalars (or NULL = 1): power-of-two scales of p, q0, q1
+    const float* sq0;
+    const float* sq1;
+    int B, T, Cp, Q0, Q1, ntaps;
+    int shift[VQW_MAX_TAPS];
+    int nsplit, pairs_row, pairs_total, n_nt;
+};
+
+__device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
+    u16 a[4], b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xs = v[e] * sc;
+        const _Float16 h1 = (_Float16)xs;
+        a[e] = f16_bits(h1);
+        b[e] = f16_bits((_Float16)(xs - (float)h1));
+    }
+    lo = make_uint2(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16));
+    return make_uint2(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16));
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int tile = blockIdx.x / a.nsplit, split = blockIdx.x - tile * a.nsplit;
+    const int mt = tile / a.n_nt, nt = tile - mt * a.n_nt;
+    const int cpt = a.Cp / 256;                       // 256-row tiles per tap
+    const int tap = mt / cpt, c0 = (mt - tap * cpt) * 256;
+    const int shift = a.shift[tap];
+    const int o0 = nt * 256;
+    const bool from_q1 = o0 >= a.Q0;
+    const float* qsrc = from_q1 ? a.q1 : a.q0;
+    const int Qs = from_q1 ? a.Q1 : a.Q0, oq = from_q1 ? o0 - a.Q0 : o0;
+    const float scp = dev_scale(a.sp), scq = dev_scale(from_q1 ? a.sq1 : a.sq0);
+    const int T = a.T;
+    const int s_begin = (int)((long)split * a.pairs_total / a.nsplit), s_end = (int)((long)(split + 1) * a.pairs_total / a.nsplit);
+    const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(a.p, (unsigned)((size_t)a.B * a.Cp * T * 4));
+    const __amdgpu_buffer_rsrc_t rq = vqw_make_rsrc(qsrc, (unsigned)((size_t)a.B * Qs * T * 4));
+
+    // One load instruction of a wave = 32 rows x 32 bytes (lane -> row lane/2, 16-byte half lane%2); instruction n of a
+    // thread: 32-row group g = wv*2 + n/4, quarter nn = n%4 of the 128-byte line = stage nn/2 of the pair, k half nn%2.
+    // The four quarters of a line are requested back to back, so the line is fetched once.
+    f32x4 rgp[8], rgq[8];
+    const int rsub = lane >> 1, hsel = lane & 1;
+    auto issue = [&](int s) {
+        const int b = s / a.pairs_row, t0 = (s - b * a.pairs_row) * 32;
+        const bool careful = (t0 + shift < 0) && (t0 + shift + 32 > 0) && (shift & 3);   // block-uniform: a 16-byte window straddles t = 0
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int g = wv * 2 + (n >> 2), nn = n & 3;
+            const int row = g * 32 + rsub;
+            const int tq = t0 + 8 * nn + 4 * hsel;
+            rgq[n] = vqw_buf_load4(rq, (int)((((size_t)b * Qs + oq + row) * T + tq) * 4), 0);
+            const int tp = tq + shift;
+            const size_t prow = ((size_t)b * a.Cp + c0 + row) * T;
+            if (!careful) {
+                rgp[n] = vqw_buf_load4(rp, tp >= 0 ? (int)((prow + tp) * 4) : (int)0x80000000, 0);   // shift <= 0: never past the row's end
+            } else {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (tp + e >= 0) ? a.p[prow + tp + e] : 0.0f;
+                rgp[n] = v;
+            }
+        }
+    };
+    auto commit = [&](int pair) {     // raw registers -> two fp16 planes -> LDS stages (2 pair) % 4 and (2 pair + 1) % 4
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int g = wv * 2 + (n >> 2), nn = n & 3;
+            char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STG_BYTES + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
+            uint2 lo;
+            uint2 hi = split4(rgp[n], scp, lo);
+            *reinterpret_cast<uint2*>(st + (g * 2 + 0) * 1024) = hi;
+            *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
+            hi = split4(rgq[n], scq, lo);
+            *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 0) * 1024) = hi;
+            *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
+        }
+    };
+    struct Frags { uint4 a[8][2], b[2][2]; };
+    auto read_frags = [&](Frags& f, int stage) {
+        const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) f.a[i][pl] = *reinterpret_cast<const uint4*>(st + (i * 2 + pl) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) f.b[j][pl] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + pl) * 1024);
+    };
+    f32x16 acc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfma16 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {   // small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][0]), __builtin_bit_cast(f16x8, f.b[j][1]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][1]), __builtin_bit_cast(f16x8, f.b[j][0]), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][0]), __builtin_bit_cast(f16x8, f.b[j][0]), acc[i][j], 0, 0, 0);
+            }
+    };
+
+    const int npairs = s_end - s_begin;
+    if (npairs > 0) {
+        issue(s_begin);
+        commit(0);
+        if (npairs > 1) issue(s_begin + 1);
+        __syncthreads();
+        Frags f;
+        for (int it = 0; it < npairs; ++it) {
+            // stages of pair `it` are in LDS; the registers hold the raw operands of pair it + 1 (requested one iteration ago)
+            read_frags(f, 2 * it);
+            mfma16(f);
+            read_frags(f, 2 * it + 1);
+            mfma16(f);
+            if (it + 1 < npairs) commit(it + 1);       // into the stages pair it - 1 was read from (behind last iteration's barrier)
+            if (it + 2 < npairs) issue(s_begin + it + 2);
+            __syncthreads();
+        }
+    }
+    // ---- partial tile -> slab [tile][split][256][256], rows c, columns o (32 lanes = 128 contiguous bytes)
+    const float inv = __builtin_amdgcn_rcpf(scp * scq);
+    float* out = a.slab + ((size_t)tile * a.nsplit + split) * 65536;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    out[(32 * i + 8 * v4 + 4 * lhi + e) * 256 + 64 * wv + 32 * j + l31] = acc[i][j][v4 * 4 + e] * inv;
+}
+
+// dW[tap][c][o] += sum over splits (fixed order) of the slab tiles
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int n_nt, int cpt, int Cp,
+                                    long lddw, long dw_tap_stride) {
+    const int tile = blockIdx.y;
+    const int mt = tile / n_nt, nt = tile - mt * n_nt;
+    const int tap = mt / cpt, c0 = (mt - tap * cpt) * 256;
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;     // 4 consecutive columns
+    if (idx >= 65536) return;
+    const int r = idx >> 8, col = idx & 255;
+    const float* sp = slab + (size_t)tile * nsplit * 65536 + idx;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; ++k) sum += *reinterpret_cast<const f32x4*>(sp + (size_t)k * 65536);
+    float* d = dw + (size_t)tap * dw_tap_stride + (size_t)(c0 + r) * lddw + nt * 256 + col;
+    f32x4 old = *reinterpret_cast<const f32x4*>(d);
+    *reinterpret_cast<f32x4*>(d) = old + sum;
+}
+
 }  // namespace
 
 extern "C" {
@@ -609,6 +787,45 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
     const int blocks = (d.R / 128) * (a.NB / 256);
     hipLaunchKernelGGL(gate_f16x3_kernel, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_gate_conv");
+    return 0;
+}
+
+
+int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(dp, "vqw_f16x3_wgrad: null descriptor");
+    const vqw_f16x3_wgrad_desc& d = *dp;
+    VQW_CHECK(d.p && d.q0 && d.dw && d.slab, "vqw_f16x3_wgrad: null operand");
+    VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 32 == 0, "vqw_f16x3_wgrad: T must be a positive multiple of 32 (got %d)", d.T);
+    VQW_CHECK(d.Cp > 0 && d.Cp % 256 == 0 && d.Q0 > 0 && d.Q0 % 256 == 0 && d.Q1 >= 0 && d.Q1 % 256 == 0 && (d.Q1 == 0 || d.q1),
+              "vqw_f16x3_wgrad: Cp, Q0, Q1 must be multiples of 256 (Cp=%d Q0=%d Q1=%d)", d.Cp, d.Q0, d.Q1);
+    VQW_CHECK(d.ntaps >= 1 && d.ntaps <= VQW_MAX_TAPS, "vqw_f16x3_wgrad: 1..%d taps", VQW_MAX_TAPS);
+    for (int j = 0; j < d.ntaps; ++j)
+        VQW_CHECK(d.tap_shift[j] <= 0 && d.tap_shift[j] > -(1 << 24), "vqw_f16x3_wgrad: tap shifts must be <= 0 (tap %d: %d)", j, d.tap_shift[j]);
+    const size_t pbytes = (size_t)d.B * d.Cp * d.T * 4, qbytes = (size_t)d.B * (d.Q0 > d.Q1 ? d.Q0 : d.Q1) * d.T * 4;
+    VQW_CHECK(pbytes < ((size_t)1 << 31) && qbytes < ((size_t)1 << 31), "vqw_f16x3_wgrad: operands exceed 2 GiB");
+    const int lddw = d.lddw > 0 ? d.lddw : d.Q0 + d.Q1;
+    VQW_CHECK(lddw >= d.Q0 + d.Q1 && lddw % 4 == 0 && (reinterpret_cast<uintptr_t>(d.dw) & 15u) == 0, "vqw_f16x3_wgrad: dw must be 16-byte aligned, lddw a multiple of 4");
+    WgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = d.p; a.q0 = d.q0; a.q1 = d.q1; a.slab = d.slab; a.sp = d.p_scale; a.sq0 = d.q0_scale; a.sq1 = d.q1_scale;
+    a.B = d.B; a.T = d.T; a.Cp = d.Cp; a.Q0 = d.Q0; a.Q1 = d.Q1; a.ntaps = d.ntaps;
+    for (int j = 0; j < d.ntaps; ++j) a.shift[j] = d.tap_shift[j];
+    a.pairs_row = d.T / 32; a.pairs_total = d.B * a.pairs_row;
+    a.n_nt = (d.Q0 + d.Q1) / 256;
+    const int tiles = d.ntaps * (d.Cp / 256) * a.n_nt;
+    int nsplit = d.nsplit > 0 ? d.nsplit : vqw_device_cus() / tiles;     // one round of blocks
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > a.pairs_total) nsplit = a.pairs_total;
+    a.nsplit = nsplit;
+    VQW_CHECK((size_t)tiles * nsplit * 65536 <= (size_t)d.slab_floats, "vqw_f16x3_wgrad: slab too small (%d tiles x %d splits x 65536 floats)", tiles, nsplit);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+        return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
+    hipLaunchKernelGGL(wgrad_f16x3_kernel, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
+    const long tap_stride = d.dw_tap_stride > 0 ? (long)d.dw_tap_stride : (long)d.Cp * lddw;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(65536 / 4 / 256, tiles), dim3(256), 0, st, d.slab, d.dw, nsplit, a.n_nt, d.Cp / 256, d.Cp,
+                       (long)lddw, tap_stride);
+    VQW_LAUNCH_CHECK("vqw_f16x3_wgrad");
     return 0;
 }
 

@@ -597,6 +597,9 @@ class VQVAE:
         flag = self.x3_flag if gd else None
         GS = 1.0 if gd else float(2 ** 20)      # guarded: the gradient scales live on the device
         WS = 1.0 if gd else 256.0
+        wg_x3 = gd and gbwd_x3 and T % 32 == 0 and os.environ.get('VQW_WGRAD_X3', '1') != '0'
+        if wg_x3 and 'wslab' not in ws:
+            ws['wslab'] = torch.empty(256 * 65536, device=self.dev)      # partial 256x256 tiles of one launch (tiles x K splits <= CUs)
         if dgrad_x3:
             K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, WS, count=L, scale_dev=sc('WG'))
         if gbwd_x3:
@@ -650,12 +653,20 @@ class VQVAE:
             with torch.cuda.stream(side):
                 if side is not main:
                     side.wait_event(ready)
-                K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
-                             Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
+                if wg_x3:    # weight gradients on the fp16 pipe too: operands split in registers with the planes' guard scales
+                    K.f16x3_wgrad(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], slab=ws['wslab'], B=B,
+                                  T=T, Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0], q0_scale=sc('G'), q1_scale=sc('G'))
+                else:
+                    K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
+                                 Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
                 if not top:
                     K.rowsum(dnet, total=G['out_b'][l][S:])
-                K.wgrad_gemm(p=net[l], q0=dpre, dw=G['gated_w'][l], B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
-                             taps=[-(ks - 1 - j) * d for j in range(ks)])
+                if wg_x3:
+                    K.f16x3_wgrad(p=net[l], q0=dpre, dw=G['gated_w'][l], slab=ws['wslab'], B=B, T=T, Cp=R, Q0=2 * R,
+                                  taps=[-(ks - 1 - j) * d for j in range(ks)], p_scale=sc('X', l), q0_scale=sc('DP', l))
+                else:
+                    K.wgrad_gemm(p=net[l], q0=dpre, dw=G['gated_w'][l], B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
+                                 taps=[-(ks - 1 - j) * d for j in range(ks)])
                 K.rowsum(dpre, seg_out=seg_l, total=G['gated_b'][l], seg=ratio)
                 dce[:, l * 2 * R:(l + 1) * 2 * R].copy_(seg_l)
                 if side is not main:
