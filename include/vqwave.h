@@ -403,7 +403,8 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
  * fp16 planes inside the kernel, with the power-of-two guard scales *_scale (device scalars or NULL) of the same tensors'
  * planes, whose producers range-check them).  T % 32 == 0; Cp, Q0, Q1 multiples of 256; tap_shift <= 0 (reads outside
  * [0, T) are zero).  `slab` is scratch: tiles * nsplit * 65536 floats (tiles = ntaps * Cp/256 * (Q0+Q1)/256; nsplit 0 =
- * CUs / tiles): partial tiles are summed in a fixed order by a second launch -- dw is bitwise reproducible.          */
+ * CUs / tiles): partial tiles are summed in a fixed order by a second launch -- dw is bitwise reproducible (q_total /
+ * q_seg are met by fp32 atomics).                                                                                  */
 typedef struct vqw_f16x3_wgrad_desc {
     const float* p;
     const float* q0;
@@ -419,6 +420,13 @@ typedef struct vqw_f16x3_wgrad_desc {
     int32_t lddw;           /* 0 = Q0 + Q1                                                                  */
     int32_t nsplit;         /* 0 = one round of blocks                                                      */
     int64_t dw_tap_stride;  /* 0 = Cp * lddw                                                                */
+    /* optional sums of q over time, formed from the registers that hold q anyway (no extra pass over q):           */
+    float* q_total;         /* q_total[o] += sum_{b,t} q[b][o][t] for o in [total_o0, total_o1) (bias gradients)     */
+    float* q_seg;           /* q_seg[b*seg_bstride + o*seg_T + t/(T/seg_T)] += q[b][o][t]: the gradient of add_condition's
+                             * projected condition (wavenet_ops.py:98-100); (T/seg_T) % 32 == 0; the caller zeroes it    */
+    int64_t seg_bstride;
+    int32_t seg_T;
+    int32_t total_o0, total_o1;   /* 0, 0 = all of [0, Q0 + Q1)                                              */
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
 

@@ -516,6 +516,23 @@ def test_wgrad_f16x3_matches_fp64(K, B, T, d, Q1, scaled):
     err = (got.double() - want).abs().max().item()
     assert err <= 2e-6 * max(upd, 1e-30) + 1e-6 * dw0.abs().max().item(), 'max err %.3e of update %.3e' % (err, upd)
     assert torch.equal(run(), got), 'dw is not bitwise reproducible'
+    # the sums of q that ride along: bias gradients (a column range) and the per-frame sums of add_condition's transpose
+    Q = Q0 + Q1
+    seg_T = T // 32
+    bst = (Q + 5) * seg_T                                   # a batch stride wider than the rows written
+    tot0 = torch.randn(Q, generator=gen).to(DEV)
+    tot, seg = tot0.clone(), torch.zeros(B * bst, device=DEV)
+    cols = (Q0, Q) if Q1 else (0, Q)
+    K.f16x3_wgrad(p=p, q0=q0, q1=q1, Q1=Q1, dw=dw0.clone(), slab=slab, B=B, T=T, Cp=Cp, Q0=Q0, taps=taps, p_scale=sc[0:1],
+                  q0_scale=sc[1:2], q1_scale=sc[2:3] if Q1 else None, q_total=tot, total_cols=cols, q_seg=seg, seg_T=seg_T,
+                  seg_bstride=bst)
+    want_tot = tot0.double().clone()
+    want_tot[cols[0]:cols[1]] += q.sum((0, 2))[cols[0]:cols[1]]
+    assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item()
+    want_seg = q.reshape(B, Q, seg_T, 32).sum(-1)
+    got_seg = seg.view(B, Q + 5, seg_T)
+    assert (got_seg[:, :Q].double() - want_seg).abs().max().item() <= 1e-5 * q.abs().max().item() * 32
+    assert float(got_seg[:, Q:].abs().max()) == 0.0
 
 
 def test_wgrad_f16x3_full_size_matches_fp32_engine(K):

@@ -519,6 +519,12 @@ struct WgArgs {
     int B, T, Cp, Q0, Q1, ntaps;
     int shift[VQW_MAX_TAPS];
     int nsplit, pairs_row, pairs_total, n_nt;
+    // sums of q over time, formed from the registers that hold q anyway (blocks of the first row tile only):
+    float* q_total;       // [Q0 + Q1] += sum_{b,t} q[b][o][t]  (bias gradients) or NULL
+    float* q_seg;         // [B][seg_bstride/..]: q_seg[b * seg_bstride + o * seg_T + t / seg_ratio] += q[b][o][t] (the transpose of
+    long seg_bstride;     //   add_condition's upsampling, wavenet_ops.py:98-100) or NULL; seg_ratio % 32 == 0
+    int seg_T, seg_ratio;
+    int total_o0, total_o1;   // q_total covers columns [total_o0, total_o1) only (e.g. the residual rows S..S+R)
 };
 
 __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
@@ -534,6 +540,8 @@ __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
     return make_uint2(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16));
 }
 
+// ODD: some tap shift is not a multiple of 4 (compile-time: a branch would cut the loop body into scheduling regions)
+template <bool ODD>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -552,57 +560,78 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(a.p, (unsigned)((size_t)a.B * a.Cp * T * 4));
     const __amdgpu_buffer_rsrc_t rq = vqw_make_rsrc(qsrc, (unsigned)((size_t)a.B * Qs * T * 4));
 
-    // One load instruction of a wave = 32 rows x 32 bytes (lane -> row lane/2, 16-byte half lane%2); instruction n of a
+    // One load instruction of a wave = 32 rows x 32 bytes (lane -> row lane/2, 16-byte half lane%2); chunk n of a
     // thread: 32-row group g = wv*2 + n/4, quarter nn = n%4 of the 128-byte line = stage nn/2 of the pair, k half nn%2.
     // The four quarters of a line are requested back to back, so the line is fetched once.
     f32x4 rgp[8], rgq[8];
     const int rsub = lane >> 1, hsel = lane & 1;
-    auto issue = [&](int s) {
-        const int b = s / a.pairs_row, t0 = (s - b * a.pairs_row) * 32;
-        const bool careful = (t0 + shift < 0) && (t0 + shift + 32 > 0) && (shift & 3);   // block-uniform: a 16-byte window straddles t = 0
+    int pb = 0, pt0 = 0;                                // batch row / first time step of the pair being requested
+    auto issue_one = [&](int n) {
+        const int g = wv * 2 + (n >> 2), nn = n & 3;
+        const int row = g * 32 + rsub;
+        const int tq = pt0 + 8 * nn + 4 * hsel;
+        rgq[n] = vqw_buf_load4(rq, (int)((((size_t)pb * Qs + oq + row) * T + tq) * 4), 0);
+        const int tp = tq + shift;                      // shift <= 0: never past the row's end
+        const size_t prow = ((size_t)pb * a.Cp + c0 + row) * T;
+        // a 16-byte window that straddles t = 0 (only with shifts that are not multiples of 4) is read from t = 0 and moved
+        // up inside the register below; windows entirely before t = 0 read as zero through the buffer range check
+        const int tl = tp >= 0 ? tp : (tp > -4 ? 0 : -1);
+        f32x4 w = vqw_buf_load4(rp, tl >= 0 ? (int)((prow + tl) * 4) : (int)0x80000000, 0);
+        if (ODD) {
+            const int k = (tp < 0 && tp > -4) ? -tp : 0;
+            f32x4 v;
+            v[0] = k == 0 ? w[0] : 0.0f;
+            v[1] = k == 0 ? w[1] : (k == 1 ? w[0] : 0.0f);
+            v[2] = k == 0 ? w[2] : (k == 1 ? w[1] : (k == 2 ? w[0] : 0.0f));
+            v[3] = k == 0 ? w[3] : (k == 1 ? w[2] : (k == 2 ? w[1] : w[0]));
+            w = v;
+        }
+        rgp[n] = w;
+    };
+    auto set_pair = [&](int s) { pb = s / a.pairs_row; pt0 = (s - pb * a.pairs_row) * 32; };
+    auto commit_one = [&](int n, int pair) {     // raw registers -> two fp16 planes -> LDS stage (2 pair + nn/2) % 4
+        const int g = wv * 2 + (n >> 2), nn = n & 3;
+        char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STG_BYTES + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
+        uint2 lo;
+        uint2 hi = split4(rgp[n], scp, lo);
+        *reinterpret_cast<uint2*>(st + (g * 2 + 0) * 1024) = hi;
+        *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
+        hi = split4(rgq[n], scq, lo);
+        *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 0) * 1024) = hi;
+        *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
+    };
+    // q sums (bias / condition gradients): the thread's two q rows (groups wv*2 and wv*2+1), its half of the 32 steps
+    const bool do_sum = mt == 0 && (a.q_seg != nullptr || (a.q_total != nullptr && o0 < a.total_o1 && o0 + 256 > a.total_o0));
+    float qs_pair[2] = {0.f, 0.f}, qs_tot[2] = {0.f, 0.f};
+    auto sum_one = [&](int n) {            // called with commit_one(n): rgq[n] still holds the raw fp32 values
+        const f32x4 v = rgq[n];
+        qs_pair[n >> 2] += (v[0] + v[1]) + (v[2] + v[3]);
+    };
+    auto flush_pair = [&](int s) {         // pair s is complete in qs_pair: add it to its condition frame, fold it into the totals
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int g = wv * 2 + (n >> 2), nn = n & 3;
-            const int row = g * 32 + rsub;
-            const int tq = t0 + 8 * nn + 4 * hsel;
-            rgq[n] = vqw_buf_load4(rq, (int)((((size_t)b * Qs + oq + row) * T + tq) * 4), 0);
-            const int tp = tq + shift;
-            const size_t prow = ((size_t)b * a.Cp + c0 + row) * T;
-            if (!careful) {
-                rgp[n] = vqw_buf_load4(rp, tp >= 0 ? (int)((prow + tp) * 4) : (int)0x80000000, 0);   // shift <= 0: never past the row's end
-            } else {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (tp + e >= 0) ? a.p[prow + tp + e] : 0.0f;
-                rgp[n] = v;
+        for (int h = 0; h < 2; ++h) {
+            const float both = qs_pair[h] + __shfl_xor(qs_pair[h], 1, 64);      // the partner lane holds the other 16 steps
+            qs_tot[h] += qs_pair[h];
+            qs_pair[h] = 0.f;
+            if (a.q_seg && hsel == 0) {
+                const int b = s / a.pairs_row, t0 = (s - b * a.pairs_row) * 32;
+                const int row = o0 + (wv * 2 + h) * 32 + rsub;
+                unsafeAtomicAdd(a.q_seg + (size_t)b * a.seg_bstride + (size_t)row * a.seg_T + t0 / a.seg_ratio, both);
             }
         }
     };
-    auto commit = [&](int pair) {     // raw registers -> two fp16 planes -> LDS stages (2 pair) % 4 and (2 pair + 1) % 4
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int g = wv * 2 + (n >> 2), nn = n & 3;
-            char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STG_BYTES + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
-            uint2 lo;
-            uint2 hi = split4(rgp[n], scp, lo);
-            *reinterpret_cast<uint2*>(st + (g * 2 + 0) * 1024) = hi;
-            *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
-            hi = split4(rgq[n], scq, lo);
-            *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 0) * 1024) = hi;
-            *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
-        }
-    };
-    struct Frags { uint4 a[8][2], b[2][2]; };
-    auto read_frags = [&](Frags& f, int stage) {
+    uint4 fa[8][2], fb[2][2], fb2[2][2];             // A fragments (both planes) of 8 row tiles, B fragments of this wave's 2 column tiles
+    auto read_a = [&](int i, int stage) {
         const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) f.a[i][pl] = *reinterpret_cast<const uint4*>(st + (i * 2 + pl) * 1024);
+        fa[i][0] = *reinterpret_cast<const uint4*>(st + (i * 2 + 0) * 1024);
+        fa[i][1] = *reinterpret_cast<const uint4*>(st + (i * 2 + 1) * 1024);
+    };
+    auto read_b = [&](uint4 (&b)[2][2], int stage) {
+        const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16 + 16 * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) f.b[j][pl] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + pl) * 1024);
+            for (int pl = 0; pl < 2; ++pl) b[j][pl] = *reinterpret_cast<const uint4*>(st + ((wv * 2 + j) * 2 + pl) * 1024);
     };
     f32x16 acc[8][2];
 #pragma unroll
@@ -611,33 +640,76 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto mfma16 = [&](const Frags& f) {
+    auto mfma_row = [&](int i, const uint4 (&b)[2][2]) {       // 6 MFMAs: row tile i x this wave's 2 column tiles, small terms first
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {   // small terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][0]), __builtin_bit_cast(f16x8, f.b[j][1]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][1]), __builtin_bit_cast(f16x8, f.b[j][0]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][0]), __builtin_bit_cast(f16x8, f.b[j][0]), acc[i][j], 0, 0, 0);
-            }
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, b[j][1]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][1]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
+        }
     };
 
     const int npairs = s_end - s_begin;
     if (npairs > 0) {
-        issue(s_begin);
-        commit(0);
-        if (npairs > 1) issue(s_begin + 1);
+        set_pair(s_begin);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) issue_one(n);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) { commit_one(n, 0); sum_one(n); }
+        if (do_sum) flush_pair(s_begin);
+        set_pair(s_begin + 1);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) issue_one(n);
         __syncthreads();
-        Frags f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) read_a(i, 0);
+        read_b(fb, 0);
         for (int it = 0; it < npairs; ++it) {
-            // stages of pair `it` are in LDS; the registers hold the raw operands of pair it + 1 (requested one iteration ago)
-            read_frags(f, 2 * it);
-            mfma16(f);
-            read_frags(f, 2 * it + 1);
-            mfma16(f);
-            if (it + 1 < npairs) commit(it + 1);       // into the stages pair it - 1 was read from (behind last iteration's barrier)
-            if (it + 2 < npairs) issue(s_begin + it + 2);
+            // Stages 2it, 2it+1 (pair `it`) are in LDS, the fragments of stage 2it in registers; the raw operands of pair
+            // it+1 are in rgp / rgq (requested one iteration ago).  Row tile by row tile: 6 MFMAs of the first stage, behind
+            // them the tile's fragments of the second stage are fetched and one chunk of pair it+1 is converted and written
+            // to the two LDS stages pair it-1 was read from; then the second stage's MFMAs with the requests of pair it+2
+            // behind them.  VALU / LDS / VMEM work is issued in the shadow of the MFMAs.
+            // (No conditionals inside: past the block's last pair the conversion rewrites stale registers into LDS stages
+            // nobody reads again and the requests fall behind the end of the buffers, where raw buffer loads return zero --
+            // branches would cut the body into scheduling regions and the MFMAs could no longer be interleaved.)
+            read_b(fb2, 2 * it + 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mfma_row(i, fb);
+                read_a(i, 2 * it + 1);
+                commit_one(i, it + 1);
+                sum_one(i);
+#pragma unroll
+                for (int k_ = 0; k_ < 6; ++k_) {          // 1 MFMA, then ~1/6 of the group's VALU / LDS work in its shadow
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200, 12, 0);
+                }
+            }
+            if (do_sum && it + 1 < npairs) flush_pair(s_begin + it + 1);
+            set_pair(s_begin + it + 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mfma_row(i, fb2);
+                issue_one(i);
+#pragma unroll
+                for (int k_ = 0; k_ < 6; ++k_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x020, 6, 0);
+                }
+            }
             __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) read_a(i, 2 * it + 2);
+            read_b(fb, 2 * it + 2);
+        }
+    }
+    if (do_sum && a.q_total) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float both = qs_tot[h] + __shfl_xor(qs_tot[h], 1, 64);
+            const int row = o0 + (wv * 2 + h) * 32 + rsub;
+            if (hsel == 0 && row >= a.total_o0 && row < a.total_o1) unsafeAtomicAdd(a.q_total + row, both);
         }
     }
     // ---- partial tile -> slab [tile][split][256][256], rows c, columns o (32 lanes = 128 contiguous bytes)
@@ -664,8 +736,21 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     if (idx >= 65536) return;
     const int r = idx >> 8, col = idx & 255;
     const float* sp = slab + (size_t)tile * nsplit * 65536 + idx;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nsplit; ++k) sum += *reinterpret_cast<const f32x4*>(sp + (size_t)k * 65536);
+    // four running sums (splits k = 0, 1, 2, 3 mod 4), combined at the end: a FIXED order, eight loads in flight per thread
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + (size_t)(k + u) * 65536));
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+    }
+    for (; k < nsplit; ++k) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + (size_t)k * 65536));
+        switch (k & 3) { case 0: s0 += v; break; case 1: s1 += v; break; case 2: s2 += v; break; default: s3 += v; }
+    }
+    const f32x4 sum = (s0 + s1) + (s2 + s3);
     float* d = dw + (size_t)tap * dw_tap_stride + (size_t)(c0 + r) * lddw + nt * 256 + col;
     f32x4 old = *reinterpret_cast<const f32x4*>(d);
     *reinterpret_cast<f32x4*>(d) = old + sum;
@@ -818,10 +903,22 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     if (nsplit < 1) nsplit = 1;
     if (nsplit > a.pairs_total) nsplit = a.pairs_total;
     a.nsplit = nsplit;
+    a.q_total = d.q_total; a.q_seg = d.q_seg; a.seg_bstride = (long)d.seg_bstride; a.seg_T = d.seg_T;
+    a.total_o0 = d.total_o0; a.total_o1 = d.total_o1 > 0 ? d.total_o1 : d.Q0 + d.Q1;
+    a.seg_ratio = 1;
+    if (d.q_seg) {
+        VQW_CHECK(d.seg_T > 0 && d.T % d.seg_T == 0 && (d.T / d.seg_T) % 32 == 0 && d.seg_bstride >= (int64_t)(d.Q0 + d.Q1) * d.seg_T,
+                  "vqw_f16x3_wgrad: q_seg needs T / seg_T to be a multiple of 32 (T=%d seg_T=%d)", d.T, d.seg_T);
+        a.seg_ratio = d.T / d.seg_T;
+    }
     VQW_CHECK((size_t)tiles * nsplit * 65536 <= (size_t)d.slab_floats, "vqw_f16x3_wgrad: slab too small (%d tiles x %d splits x 65536 floats)", tiles, nsplit);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+    bool odd = false;
+    for (int j = 0; j < d.ntaps; ++j) odd |= (d.tap_shift[j] & 3) != 0;
+    const void* kfn = odd ? reinterpret_cast<const void*>(wgrad_f16x3_kernel<true>) : reinterpret_cast<const void*>(wgrad_f16x3_kernel<false>);
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-    hipLaunchKernelGGL(wgrad_f16x3_kernel, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
+    if (odd) hipLaunchKernelGGL(wgrad_f16x3_kernel<true>, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
+    else hipLaunchKernelGGL(wgrad_f16x3_kernel<false>, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
     const long tap_stride = d.dw_tap_stride > 0 ? (long)d.dw_tap_stride : (long)d.Cp * lddw;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(65536 / 4 / 256, tiles), dim3(256), 0, st, d.slab, d.dw, nsplit, a.n_nt, d.Cp / 256, d.Cp,
                        (long)lddw, tap_stride);

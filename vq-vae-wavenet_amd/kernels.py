@@ -325,7 +325,7 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
 
 
 def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
-                q0_scale=None, q1_scale=None):
+                q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0):
     """vqw_f16x3_wgrad: dw[j][c][o] += sum_{b,t} p[b][c][t+taps[j]] * q[b][o][t] on the fp16x3 engine (slab = scratch)."""
     lddw = (Q0 + Q1) if lddw is None else lddw
     dw_tap_stride = Cp * lddw if dw_tap_stride is None else dw_tap_stride
@@ -343,6 +343,14 @@ def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None
     for j, sh in enumerate(taps):
         d.tap_shift[j] = int(sh)
     d.lddw, d.nsplit, d.dw_tap_stride = lddw, nsplit, dw_tap_stride
+    if q_total is not None:      # q_total[o] += sum_{b,t} q[b][o][t] for o in total_cols = (o0, o1)
+        o0, o1 = total_cols if total_cols is not None else (0, Q0 + Q1)
+        _need(q_total, o1, 'q_total')
+        d.q_total, d.total_o0, d.total_o1 = q_total.data_ptr(), o0, o1
+    if q_seg is not None:        # q_seg[b][o][t / (T / seg_T)] += q[b][o][t] (batch stride seg_bstride); zeroed by the caller
+        seg_bstride = seg_bstride or (Q0 + Q1) * seg_T
+        _need(q_seg, (B - 1) * seg_bstride + (Q0 + Q1) * seg_T, 'q_seg')
+        d.q_seg, d.seg_T, d.seg_bstride = q_seg.data_ptr(), seg_T, seg_bstride
     L.check(L.lib().vqw_f16x3_wgrad(C.byref(d), L.stream()))
 
 

@@ -609,6 +609,8 @@ class VQVAE:
                                       amax=am('G'), flag=flag)   # one tensor for all layers
         if calib:
             K.f16x3_amax(dskip, am('G'))
+        if wg_x3:      # the weight-gradient kernels add the per-frame sums of dpre into the condition gradient
+            dce[:, :L * 2 * R].zero_()
         side_done = {}
         dnet = dnet_ring[(L - 1) % 3]
         for l in range(L - 1, -1, -1):
@@ -653,28 +655,33 @@ class VQVAE:
             with torch.cuda.stream(side):
                 if side is not main:
                     side.wait_event(ready)
-                if wg_x3:    # weight gradients on the fp16 pipe too: operands split in registers with the planes' guard scales
+                if wg_x3:    # weight gradients on the fp16 pipe too: operands split in registers with the planes' guard scales;
+                    # the bias sums and the condition gradient (sums of dpre per condition frame) come out of the same kernels
                     K.f16x3_wgrad(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], slab=ws['wslab'], B=B,
-                                  T=T, Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0], q0_scale=sc('G'), q1_scale=sc('G'))
+                                  T=T, Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0], q0_scale=sc('G'), q1_scale=sc('G'),
+                                  q_total=None if top else G['out_b'][l], total_cols=(S, S + R))
+                    K.f16x3_wgrad(p=net[l], q0=dpre, dw=G['gated_w'][l], slab=ws['wslab'], B=B, T=T, Cp=R, Q0=2 * R,
+                                  taps=[-(ks - 1 - j) * d for j in range(ks)], p_scale=sc('X', l), q0_scale=sc('DP', l),
+                                  q_seg=dce.view(-1)[l * 2 * R * Tz:], seg_T=Tz, seg_bstride=cbs)
                 else:
                     K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
                                  Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
-                if not top:
-                    K.rowsum(dnet, total=G['out_b'][l][S:])
-                if wg_x3:
-                    K.f16x3_wgrad(p=net[l], q0=dpre, dw=G['gated_w'][l], slab=ws['wslab'], B=B, T=T, Cp=R, Q0=2 * R,
-                                  taps=[-(ks - 1 - j) * d for j in range(ks)], p_scale=sc('X', l), q0_scale=sc('DP', l))
-                else:
+                    if not top:
+                        K.rowsum(dnet, total=G['out_b'][l][S:])
                     K.wgrad_gemm(p=net[l], q0=dpre, dw=G['gated_w'][l], B=B, T_q=T, T_p=T, Cp=R, Q0=2 * R,
                                  taps=[-(ks - 1 - j) * d for j in range(ks)])
-                K.rowsum(dpre, seg_out=seg_l, total=G['gated_b'][l], seg=ratio)
-                dce[:, l * 2 * R:(l + 1) * 2 * R].copy_(seg_l)
+                    K.rowsum(dpre, seg_out=seg_l, total=G['gated_b'][l], seg=ratio)
+                    dce[:, l * 2 * R:(l + 1) * 2 * R].copy_(seg_l)
                 if side is not main:
                     side_done[l] = torch.cuda.Event()
                     side_done[l].record(side)
             dnet = dnet_next
         if side is not main:
             main.wait_stream(side)
+        if wg_x3:      # gated biases: the condition gradient summed over batch and frames, all layers in one launch
+            tot = torch.zeros(self.Mall, device=self.dev)
+            K.rowsum(dce, total=tot)
+            G['gated_b'].view(-1).add_(tot[:L * 2 * R])
         # ---- skip start + preprocess (wavenet.py:42-55)
         K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
                     C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
