@@ -528,7 +528,7 @@ def test_wgrad_f16x3_matches_fp64(K, B, T, d, Q1, scaled):
                   seg_bstride=bst)
     want_tot = tot0.double().clone()
     want_tot[cols[0]:cols[1]] += q.sum((0, 2))[cols[0]:cols[1]]
-    assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item()
+    assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item() + 2e-6 * tot0.abs().max().item()   # tens of atomic adds into O(1) values
     want_seg = q.reshape(B, Q, seg_T, 32).sum(-1)
     got_seg = seg.view(B, Q + 5, seg_T)
     assert (got_seg[:, :Q].double() - want_seg).abs().max().item() <= 1e-5 * q.abs().max().item() * 32

@@ -604,6 +604,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const bool do_sum = mt == 0 && (a.q_seg != nullptr || (a.q_total != nullptr && o0 < a.total_o1 && o0 + 256 > a.total_o0));
     float qs_pair[2] = {0.f, 0.f}, qs_tot[2] = {0.f, 0.f};
     auto sum_one = [&](int n) {            // called with commit_one(n): rgq[n] still holds the raw fp32 values
+#ifdef VQW_ABL_WG_NOSUM
+        return;
+#endif
         const f32x4 v = rgq[n];
         qs_pair[n >> 2] += (v[0] + v[1]) + (v[2] + v[3]);
     };
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             }
         }
     };
-    uint4 fa[8][2], fb[2][2], fb2[2][2];             // A fragments (both planes) of 8 row tiles, B fragments of this wave's 2 column tiles
+    uint4 fa[8][2], fb[2][2];                        // A fragments (both planes) of 8 row tiles, B fragments of this wave's 2 column tiles
     auto read_a = [&](int i, int stage) {
         const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16;
         fa[i][0] = *reinterpret_cast<const uint4*>(st + (i * 2 + 0) * 1024);
@@ -673,7 +676,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             // (No conditionals inside: past the block's last pair the conversion rewrites stale registers into LDS stages
             // nobody reads again and the requests fall behind the end of the buffers, where raw buffer loads return zero --
             // branches would cut the body into scheduling regions and the MFMAs could no longer be interleaved.)
-            read_b(fb2, 2 * it + 1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 mfma_row(i, fb);
@@ -688,9 +690,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             }
             if (do_sum && it + 1 < npairs) flush_pair(s_begin + it + 1);
             set_pair(s_begin + it + 2);
+            read_b(fb, 2 * it + 1);        // (after the first stage's last use of fb: 16 registers instead of 32)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                mfma_row(i, fb2);
+                mfma_row(i, fb);
                 issue_one(i);
 #pragma unroll
                 for (int k_ = 0; k_ < 6; ++k_) {
