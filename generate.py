@@ -76,8 +76,11 @@ def main():
 
     parameters, wavenet_parameters = pkg.model.load_configs(args.parameter_path)
     model = pkg.model.VQVAE(parameters, wavenet_parameters, num_speakers, device=dev, seed=0)
-    model.load_state_dict(torch.load(args.restore_path, map_location='cpu', weights_only=True))
-    model.use_ema_weights()                    # generate.py:88-90
+    if args.restore_path.endswith(('.safetensors', '.npz')):      # TF variable names (checkpoint.py); EMA shadows -> live
+        pkg.checkpoint.load(model, args.restore_path, ema_to_live=True)
+    else:
+        model.load_state_dict(torch.load(args.restore_path, map_location='cpu', weights_only=True))
+        model.use_ema_weights()                # generate.py:88-90
     save_path = args.restore_path.split('/weights')[0]
     if rank == 0:
         np.save(save_path + '/embedding_%d.npy' % gs, model.P['embedding'].cpu().numpy())

@@ -54,6 +54,22 @@ def test_train_then_generate_roundtrip(tmp_path):
     sr, gen = wavfile.read(str(tmp_path / 'saved_model' / '4_no_speaker.wav'))
     assert sr == 16000 and gen.dtype == np.float32 and gen.shape == (1024,) and np.isfinite(gen).all()
     assert (tmp_path / 'saved_model' / '4_p226.wav').exists()
+    # the same checkpoint under the reference's TF variable names (checkpoint.py): restoring it (EMA shadows -> live
+    # variables, generate.py:88-90) generates the same samples; train.py resumes from it as well
+    st_path = tmp_path / 'saved_model' / 'weights-4.safetensors'
+    assert st_path.exists()
+    os.rename(str(tmp_path / 'saved_model' / '4_p226.wav'), str(tmp_path / 'saved_model' / 'pt_p226.wav'))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'generate.py'), '-restore', str(st_path), '-audio',
+                          str(tmp_path / 'a.wav'), '-speakers', 'p226', '-mode', 'greedy', '-params',
+                          str(tmp_path / 'm.json')], cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert np.array_equal(wavfile.read(str(tmp_path / 'saved_model' / '4_p226.wav'))[1],
+                          wavfile.read(str(tmp_path / 'saved_model' / 'pt_p226.wav'))[1])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '-dataset', 'synthetic', '-length', '512',
+                          '-batch', '2', '-step', '1', '-interval', '1', '-restore', str(st_path), '-save',
+                          'saved_model/weights', '-params', str(tmp_path / 'm.json')], cwd=cwd, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'last global step: 4' in out.stdout, out.stderr[-2000:]
     assert (tmp_path / 'saved_model' / 'embedding_4.npy').exists()
     assert np.load(str(tmp_path / 'saved_model' / 'speaker_embedding_4.npy')).shape == (109, 16)
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'generate.py'), '-restore', str(ckpt), '-audio',

@@ -54,6 +54,51 @@ def test_load_named_roundtrip_and_ema(pkg):
         model._workspace(2, 100)       # length must be a multiple of 64 (Encoder_64)
 
 
+def test_checkpoint_under_reference_variable_names(pkg, tmp_path):
+    """checkpoint.py: the whole state under the TF variable names of SURVEY Appendix B (+ /ExponentialMovingAverage shadows,
+    /Adam slots, global_step) in safetensors and npz; round trip, generate.py:88-90's shadow restore, slot-scope prefixes."""
+    from safetensors import safe_open
+    C = pkg.checkpoint
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    m.update(k=32, latent_dim=16, speaker_embedding=16, encoder_filters=48)
+    w.update(dilation_rates=[1, 2], num_cycles=1, num_cycle_layers=2, dilation_filters=32, skip_filters=64,
+             residual_filters=32, preprocess={"kernel_size": 32, "filters": 32})
+    a = pkg.model.VQVAE(m, w, 7, device='cpu', seed=1)
+    g = torch.Generator().manual_seed(0)
+    for t in (a.ema, a.adam_m, a.adam_v):
+        t.copy_(torch.randn(a.n_flat, generator=g))
+    a.bn_mean.copy_(torch.randn(a.bn_mean.numel(), generator=g))
+    a.global_step = 1234
+    ref_names = set(M.init_params(m, w, 7, seed=0))
+    for ext in ('safetensors', 'npz'):
+        path = str(tmp_path / ('weights-1234.' + ext))
+        C.save(a, path)
+        b = pkg.model.VQVAE(m, w, 7, device='cpu', seed=2)
+        used = C.load(b, path)
+        for attr in ('flat', 'ema', 'adam_m', 'adam_v', 'bn_mean', 'bn_var'):
+            assert torch.equal(getattr(a, attr), getattr(b, attr)), (ext, attr)
+        assert b.global_step == 1234 and 'global_step' in used
+    with safe_open(str(tmp_path / 'weights-1234.safetensors'), 'pt') as f:
+        keys = set(f.keys())
+        assert f.get_tensor('decoder/cycle_1/layer_2/skip/kernel').shape == (1, 32, 64)
+    trainable = {k for k in ref_names if M.is_trainable(k)}
+    assert keys == ref_names | {k + s for k in trainable for s in (C.EMA, C.M1, C.M2)} | {'global_step'}
+    c = pkg.model.VQVAE(m, w, 7, device='cpu', seed=3)
+    C.load(c, str(tmp_path / 'weights-1234.npz'), ema_to_live=True)           # generate.py:88-90
+    assert torch.equal(c.flat, a.ema)
+    # a file whose slots carry a scope prefix (as a real TF checkpoint may) and has no Adam slots
+    st = {('optimiser/' + k if k.endswith(C.EMA) else k): v.numpy() for k, v in C.named_state(a).items()
+          if not k.endswith((C.M1, C.M2))}
+    np.savez(str(tmp_path / 'tf.npz'), **st)
+    d = pkg.model.VQVAE(m, w, 7, device='cpu', seed=4)
+    C.load(d, str(tmp_path / 'tf.npz'))
+    assert torch.equal(d.ema, a.ema) and torch.equal(d.flat, a.flat) and not torch.equal(d.adam_m, a.adam_m)
+    del st['speaker_embedding']
+    np.savez(str(tmp_path / 'bad.npz'), **st)
+    with pytest.raises(KeyError):
+        C.load(d, str(tmp_path / 'bad.npz'))
+
+
 def _worker(rank, world, port, q):
     import importlib
     import torch.distributed as dist

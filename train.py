@@ -74,7 +74,10 @@ def main():
         raise NotImplementedError('encoder %s not implemented' % parameters['encoder'])
     model = pkg.model.VQVAE(parameters, wavenet_parameters, dataset.num_speakers, device=dev, seed=0)
     if args.restore_path is not None:
-        model.load_state_dict(torch.load(args.restore_path, map_location='cpu', weights_only=True))
+        if args.restore_path.endswith(('.safetensors', '.npz')):      # TF variable names (checkpoint.py)
+            pkg.checkpoint.load(model, args.restore_path)
+        else:
+            model.load_state_dict(torch.load(args.restore_path, map_location='cpu', weights_only=True))
     if world > 1:
         model.grad_sync = pkg.parallel.GradAllReduce(model.grad)
     gs, lr = model.global_step, model.lr_at(model.global_step)
@@ -99,6 +102,8 @@ def main():
         torch.cuda.synchronize()
         path = '%s-%d.pt' % (args.save_path, model.global_step)
         torch.save(model.state_dict(), path)
+        # the same state under the reference's TF variable names (+ EMA shadows, Adam slots): checkpoint.py
+        pkg.checkpoint.save(model, '%s-%d.safetensors' % (args.save_path, model.global_step))
         with open(os.path.join(save_dir, save_name + '.json'), 'w') as f:
             json.dump({'model': parameters, 'wavenet': wavenet_parameters, 'num_speakers': dataset.num_speakers}, f)
         print('\nsaved', path)

@@ -4,6 +4,6 @@ The directory name is not a Python identifier; import it with
     importlib.import_module('vq-vae-wavenet_amd')
 (the repo root on sys.path), which is what train.py / generate.py / bench.py / tests do.
 """
-from . import _lib, data, encoders, generator, graph, kernels, model, ops, parallel, utils  # noqa: F401
+from . import _lib, checkpoint, data, encoders, generator, graph, kernels, model, ops, parallel, utils  # noqa: F401
 
-__all__ = ['_lib', 'data', 'encoders', 'generator', 'graph', 'kernels', 'model', 'ops', 'parallel', 'utils']
+__all__ = ['_lib', 'checkpoint', 'data', 'encoders', 'generator', 'graph', 'kernels', 'model', 'ops', 'parallel', 'utils']
