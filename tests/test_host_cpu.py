@@ -160,6 +160,29 @@ def test_wav_dataset_and_speaker_map(pkg, tmp_path):
     xs, ss = syn.next()
     xo, so, _ = M.synthetic_batch(2, 512, 10, 1234)
     assert torch.equal(xs, xo[:, :, 0]) and torch.equal(ss, so)           # same segments as the oracle / bench
+    # a speaker id outside the table is refused where the ids are still Python ints
+    (root / 'vctk_speakers.txt').write_text('p225, 0\np226, 7\n')
+    with pytest.raises(ValueError, match='speaker ids outside'):
+        pkg.data.VCTK(4, 6656, relative_path=str(root) + '/', device='cpu', seed=1)
+    (root / 'vctk_speakers.txt').write_text('p225, 0\np226, 1\n')
+    # Prefetcher: a background thread prepares the next batches (48 kHz files are resampled there) while the consumer is
+    # busy for a step's time; same batches in the same order as the dataset alone, and the step loop never waits
+    import time
+    want = pkg.data.VCTK(8, 6656, relative_path=str(root) + '/', device='cpu', seed=5)
+    pf = pkg.data.Prefetcher(pkg.data.VCTK(8, 6656, relative_path=str(root) + '/', device='cpu', seed=5), depth=3, device='cpu')
+    t0 = time.time()
+    want.next()
+    per_batch = time.time() - t0                      # host time to build one batch
+    want = pkg.data.VCTK(8, 6656, relative_path=str(root) + '/', device='cpu', seed=5)
+    time.sleep(3 * per_batch + 0.05)                  # let the ring fill, as the model build does in train.py
+    step = max(0.059, 1.5 * per_batch)                # 59 ms per step (BENCH_r01), or slower if this host is
+    for _ in range(6):
+        xa, sa = pf.next()
+        xb, sb = want.next()
+        assert torch.equal(xa, xb) and torch.equal(sa, sb)
+        time.sleep(step)
+    assert pf.waits == 0 and pf.served == 6, 'the step loop waited %d times on the input pipeline' % pf.waits
+    pf.close()
 
 
 def test_cli_surface_matches_reference_flags():

@@ -69,6 +69,7 @@ def main():
     else:
         raise NotImplementedError('dataset %s not implemented' % args.dataset)
 
+    dataset = D.Prefetcher(dataset, depth=3, device=dev)       # WAV reading / resampling off the step loop (dataset.py:75-84)
     parameters, wavenet_parameters = pkg.model.load_configs(args.parameter_path)
     if parameters['encoder'] not in ('64', 'Magenta', '2019'):                      # train.py:52-60
         raise NotImplementedError('encoder %s not implemented' % parameters['encoder'])
@@ -107,6 +108,7 @@ def main():
         with open(os.path.join(save_dir, save_name + '.json'), 'w') as f:
             json.dump({'model': parameters, 'wavenet': wavenet_parameters, 'num_speakers': dataset.num_speakers}, f)
         print('\nsaved', path)
+    dataset.close()
     if world > 1:
         dist.destroy_process_group()
 
