@@ -199,6 +199,8 @@ def main():
     ap.add_argument('--gen-steps', type=int, default=8192, help='AR samples to generate for the generation rate (SURVEY 8(d): L >= 8192)')
     ap.add_argument('--encoder', default=None, help="override model_parameters.json's encoder ('64', 'Magenta', '2019'); "
                     "'2019' needs --length 6400 (T %% 320 == 0): BASELINE.json configs[4] in fp32")
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help="bf16: BASELINE.json configs[4] -- the decoder's contraction operands as "
+                    "bf16 planes, bf16 MFMA, fp32 accumulate (use with --encoder 2019 --length 6400)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
     ap.add_argument('--no-other-engine', action='store_true', help='skip the extra timing of the same step on the fp32-MFMA engine')
@@ -243,6 +245,8 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
 
+    if a.dtype == 'bf16':
+        os.environ['VQW_DTYPE'] = 'bf16'
     pkg = importlib.import_module('vq-vae-wavenet_amd')
     K = pkg.kernels
     m, w = default_configs()
@@ -285,7 +289,7 @@ def main():
 
     # Beside the headline: the same step on the other engine (VQW_ENGINE=fp32: the fp32-MFMA engine everywhere)
     exp = None
-    if world == 1 and not a.no_other_engine and model.x3_guard:
+    if world == 1 and not a.no_other_engine and model.x3_guard and a.dtype == 'f32':
         try:
             os.environ['VQW_ENGINE'] = 'fp32'
             try:
@@ -364,7 +368,15 @@ def main():
                          "ms_per_launch": gate_ms, "flop_per_launch": flops_gate,
                          "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
         }
-        if gate_x3:   # the fp16x3 engine ran: three fp16 MFMA terms per product, priced on the 16-bit pipe
+        if gate_x3 and model.bf16:   # BASELINE.json configs[4]: one bf16 MFMA per product
+            rec["dtype"] = ("bf16 (decoder contraction operands stored as bf16 planes, v_mfma_f32_32x32x16_bf16, fp32 accumulate; master "
+                            "weights, optimiser, residual stream, encoder, VQ and losses fp32)")
+            rec["config"]["workload"] = rec["config"]["workload"].replace("fp32,", "bf16 storage + fp32 accumulate,")
+            rec["roofline"].update({"kernel": "gate_f16x3_kernel<bf16> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; one bf16 plane per operand)",
+                                    "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                                    "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_F16_MFMA_TFLOPS * 1e12)})
+            rec["engine"] = {"name": "bf16", "steps_on_engine": model.x3_steps}
+        elif gate_x3:   # the fp16x3 engine ran: three fp16 MFMA terms per product, priced on the 16-bit pipe
             rec["dtype"] = ("f32 (storage and accumulation fp32; decoder contractions: each fp32 operand as two fp16 planes = 22 "
                             "significand bits, products h1h1 + h1h2 + h2h1 on the fp16 MFMA, device-side range guards; "
                             "encoder, head and weight gradients on the fp32 MFMA)")

@@ -312,6 +312,11 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
  * fp32 accumulators (DESIGN.md 3.2b for the error analysis and measurements).
  * Plane layout: [plane 0..1][channel chunk of 8][row][8 fp16] (16-byte entries); 2 * rows * channels bytes each.    */
 
+/* `mode` (every vqw_f16x3_* entry point / descriptor): 0 = the fp16x3 engine described above; 1 = the bf16 engine of
+ * BASELINE.json configs[4] -- bf16 storage + fp32 accumulate: ONE bf16 plane per operand (planes buffers hold only the
+ * first plane: rows * channels * 2 bytes), one v_mfma_f32_32x32x16_bf16 per product; same layouts, same kernels, no
+ * range scales needed (bf16 has fp32's exponent range).  Operands written in one mode must be consumed in the same.   */
+
 /* Range guards.  The leading plane of scale * x must stay inside fp16 (|.| <= 65504).  Scales are powers of two held in
  * DEVICE memory, chosen from measured max-abs values with no host round trip:
  *   vqw_f16x3_amax           amax[i] = max(amax[i], bits(max |x_i|)) over `count` strided matrices [rows][cols]
@@ -329,14 +334,14 @@ int vqw_f16x3_update_scales(uint32_t* amax, float* scale, int n, int target_exp,
 /* scale * scale_dev[0] * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0.  scale: 1 for activations, a
  * power of two that lifts a gradient tensor into fp16's range (undone through w_scale_inv / x_scale of the consumer) */
 int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC,
-                                const float* scale_dev, uint32_t* amax, int32_t* flag,
+                                const float* scale_dev, uint32_t* amax, int32_t* flag, int mode,
                                 vqw_stream_t s);   /* planes hold KC chunks per plane, x goes to chunks kc0.. (0, 0: KC = C/8) */
 /* w [ks][R][ldw] fp32 (kernel[k, Cin, Cout]: filter columns 0..R-1, gate columns R..2R-1), multiplied by `scale`
  * (a power of two that lifts the residual plane into fp16's normal range, e.g. 256) -> planes [2][ks*R/8][2R][8]
  * with the output channels in the kernel's block order; R % 128 == 0.  `count` layers stored back to back (w: ks*R*ldw
  * floats apart, planes: 2*ks*R*2R halves apart) are packed by one launch */
 int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count,
-                                const float* scale_dev, vqw_stream_t s);   /* planes hold scale * scale_dev[0] * w */
+                                const float* scale_dev, int mode, vqw_stream_t s);   /* planes hold scale * scale_dev[0] * w */
 
 typedef struct vqw_f16x3_gate_desc {
     const void* xp;      /* activation planes of the layer input [B][R][T]                  */
@@ -354,6 +359,7 @@ typedef struct vqw_f16x3_gate_desc {
                                              * chunk kc0 (several layers side by side); 0, 0 = exactly this layer's R/8 */
     const float* x_scale;  /* device scalars (or NULL = 1): the scales xp and wp were written with; the accumulators */
     const float* w_scale;  /* are multiplied by w_scale_inv / (x_scale * w_scale)                                    */
+    int32_t mode;          /* 0: fp16x3; 1: bf16 (see below)                                                         */
 } vqw_f16x3_gate_desc;
 /* T % 256 == 0, R % 128 == 0, (T / cond_T) % 32 == 0; tap j reads x[t - (ks-1-j)*dilation], zero before t = 0 */
 int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
@@ -361,7 +367,7 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
 /* w [K][ldw] fp32 (row k, column m), times `scale` -> planes [2][K/8][M][8]; K % 8 == 0; `count` matrices back to back
  * (w: K*ldw floats apart, planes: 2*K*M halves apart) */
 int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count,
-                           const float* scale_dev, vqw_stream_t s);
+                           const float* scale_dev, int mode, vqw_stream_t s);
 
 /* The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
  * skip[b][m][t] += (W g)[m] + bias[m] for m < S;  net_out[b][c][t] = net_in[b][c][t] + (W g)[S+c] + bias[S+c],
@@ -394,6 +400,7 @@ typedef struct vqw_f16x3_out_desc {
     const float* out_scale; /* device scalar (or NULL = 1): net_out_planes hold plane_scale * out_scale * net_out   */
     uint32_t* out_amax;    /* atomicMax of the bit pattern of max |net_out| (or NULL)                                */
     int32_t* flag;         /* |= 1 when plane_scale * out_scale * |net_out| > 65504 or net_out is not finite (or NULL) */
+    int32_t mode;          /* 0: fp16x3; 1: bf16                                                                      */
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 
@@ -427,6 +434,7 @@ typedef struct vqw_f16x3_wgrad_desc {
     int64_t seg_bstride;
     int32_t seg_T;
     int32_t total_o0, total_o1;   /* 0, 0 = all of [0, Q0 + Q1)                                              */
+    int32_t mode;           /* 0: fp16x3; 1: bf16                                                            */
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
 

@@ -259,6 +259,40 @@ def test_guarded_f16x3_engine_adversarial_ranges(pkg, monkeypatch, what):
         assert model.x3_fallbacks >= 1 and not used[0] and used[-1], (model.x3_fallbacks, used)
 
 
+@pytest.mark.parametrize('B,T', [(1, 1280), (2, 6400)])
+def test_bf16_engine_encoder_2019(pkg, monkeypatch, B, T):
+    """BASELINE.json configs[4]: the '2019' encoder (MFCC front end, T % 320 == 0) with the decoder's contractions on the
+    bf16 engine (VQW_DTYPE=bf16: one bf16 plane per operand, v_mfma_f32_32x32x16_bf16, fp32 accumulate; master weights,
+    residual stream, encoder, VQ and losses fp32) against the FP32 oracle.  bf16 carries 8 significand bits (unit
+    roundoff 2^-9 = 2e-3 per operand) through 30 residual layers, hence the stated bf16 bars: VQ indices and mu-law labels
+    still bit-exact (the encoder and the codebook search are fp32), logits 3e-2 of the tensor max, losses 5e-3,
+    gradients 8e-2 in relative L2."""
+    monkeypatch.setenv('VQW_DTYPE', 'bf16')
+    m, w = dict(M.DEFAULT_MODEL, encoder='2019'), dict(M.DEFAULT_WAVENET)
+    P = M.init_params(m, w, 251, seed=5, randomize_all=True)            # LibriSpeech: 251 speakers
+    x, spk, _ = M.synthetic_batch(B, T, 251, 77)
+    model = pkg.model.VQVAE(m, w, 251, device='cuda', seed=0)
+    model.load_named(P)
+    assert model.bf16 and model.x3_mode == 1 and not model.x3_guard
+    xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
+    st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
+    out, grads = M.train_step(x, spk, P, m, w, st, 0)
+    ws = model.forward(xd, sd, compute_grad_seed=False)
+    assert ws['x3_used'] and ws['Tz'] == T // 320
+    assert torch.equal(ws['idx'].cpu(), out['q']) and torch.equal(ws['labels'].cpu().reshape(-1), out['labels'])
+    e_logits = relerr(ws['logits'].permute(0, 2, 1).reshape(-1, model.Q), out['logits'])
+    assert e_logits < 3e-2, e_logits
+    ws = model.train_step(xd, sd)
+    loss, recon, vq, _ = model.losses(ws)
+    np.testing.assert_allclose(loss, out['loss'].item(), rtol=5e-3)
+    np.testing.assert_allclose(vq, out['vq_loss'].item(), rtol=2e-5)     # fp32 path
+    got = model.named_gradients()
+    worst = max(((l2err(got[n], g), n) for n, g in grads.items()))
+    print('bf16 engine: logits %.2e, loss %.6f vs %.6f, worst grad %.2e (%s)' % (e_logits, loss, out['loss'].item(), *worst))
+    assert worst[0] < 8e-2, worst
+    assert model.x3_steps == 1
+
+
 def test_data_parallel_shards_sum_to_full_batch(pkg):
     """Two 'ranks' with half the batch each: mean of their flat gradients == full-batch
     gradient (what the RCCL all-reduce + 1/world scaling computes)."""

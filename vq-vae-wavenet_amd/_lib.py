@@ -59,7 +59,7 @@ class F16x3GateDesc(C.Structure):
         ('out_planes', _fp), ('cond_bstride', C.c_int64),
         ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('ks', C.c_int32), ('dilation', C.c_int32),
         ('cond_T', C.c_int32), ('w_scale_inv', C.c_float), ('out_planes_kc0', C.c_int32), ('out_planes_KC', C.c_int32),
-        ('x_scale', _fp), ('w_scale', _fp),
+        ('x_scale', _fp), ('w_scale', _fp), ('mode', C.c_int32),
     ]
 
 
@@ -72,7 +72,7 @@ class F16x3OutDesc(C.Structure):
         ('ks', C.c_int32), ('dilation', C.c_int32), ('dir', C.c_int32),
         ('planes_kc0', C.c_int32), ('planes_KC', C.c_int32), ('plane_scale', C.c_float), ('epi', C.c_int32),
         ('aux0', _fp), ('aux1', _fp),
-        ('x_scale', _fp), ('w_scale', _fp), ('out_scale', _fp), ('out_amax', _fp), ('flag', _fp),
+        ('x_scale', _fp), ('w_scale', _fp), ('out_scale', _fp), ('out_amax', _fp), ('flag', _fp), ('mode', C.c_int32),
     ]
 
 class F16x3WgradDesc(C.Structure):
@@ -82,7 +82,7 @@ class F16x3WgradDesc(C.Structure):
         ('B', C.c_int32), ('T', C.c_int32), ('Cp', C.c_int32), ('Q0', C.c_int32), ('Q1', C.c_int32), ('ntaps', C.c_int32),
         ('tap_shift', C.c_int32 * MAX_TAPS), ('lddw', C.c_int32), ('nsplit', C.c_int32), ('dw_tap_stride', C.c_int64),
         ('q_total', _fp), ('q_seg', _fp), ('seg_bstride', C.c_int64), ('seg_T', C.c_int32), ('total_o0', C.c_int32),
-        ('total_o1', C.c_int32),
+        ('total_o1', C.c_int32), ('mode', C.c_int32),
     ]
 
 
@@ -129,10 +129,10 @@ SIGNATURES = {
     'vqw_ar_decode_destroy': (_i, [_fp]),
     'vqw_f16x3_amax': (_i, [_fp, _i64, _i, _i64, _i64, _i, _fp, _fp, _fp]),
     'vqw_f16x3_update_scales': (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
-    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _i, _fp, _fp, _fp, _fp]),
-    'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _fp]),
+    'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _i, _fp, _fp, _fp, _i, _fp]),
+    'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _i, _fp]),
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),
-    'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _fp]),
+    'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _i, _fp]),
     'vqw_f16x3_out_conv': (_i, [C.POINTER(F16x3OutDesc), _fp]),
     'vqw_f16x3_wgrad': (_i, [C.POINTER(F16x3WgradDesc), _fp]),
 }

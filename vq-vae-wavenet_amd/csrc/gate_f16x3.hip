@@ -26,11 +26,17 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ u16 f16_bits(_Float16 h) { return __builtin_bit_cast(u16, h); }
+__device__ __forceinline__ u16 bf16_bits(float x) { return __builtin_bit_cast(u16, (__bf16)x); }   // round to nearest even
+// BF (every template below): the bf16 engine -- ONE bf16 plane per operand, one v_mfma_f32_32x32x16_bf16 per product
+// (bf16 storage + fp32 accumulate, BASELINE.json configs[4]) instead of two fp16 planes and three fp16 MFMA terms.
+template <bool BF = false>
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& p0, uint4& p1) {
     u16 a[8], b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+        if (BF) { a[e] = bf16_bits(x[e]); b[e] = 0; continue; }
         const _Float16 h1 = (_Float16)x[e];            // round to nearest even
         a[e] = f16_bits(h1);
         b[e] = f16_bits((_Float16)(x[e] - (float)h1)); // the difference is exact in fp32
@@ -67,6 +73,7 @@ __device__ __forceinline__ void guard_report(float m, bool bad, float ps, unsign
 }
 
 // x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16 of scale * scale_dev[0] * x
+template <bool BF>
 __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T, float scale, int kc0, int KC,
                                  const float* __restrict__ scale_dev, unsigned* amax, int* flag) {
     const size_t NB = (size_t)B * T;
@@ -88,9 +95,9 @@ __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict_
             m = fmaxf(m, fabsf(xv));
         }
         uint4 p0, p1;
-        split8(v, p0, p1);
+        split8<BF>(v, p0, p1);
         planes[(size_t)(kc0 + kc) * NB + row] = p0;
-        planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
+        if (!BF) planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
     }
     guard_report(m, bad, sc, amax, flag);
 }
@@ -130,6 +137,7 @@ __global__ void update_scales_kernel(unsigned* amax, float* scale, int n, int ta
 
 // w [ks][R][ldw] (kernel[k, Cin, Cout], filter columns 0..R-1, gate columns R..2R-1) -> planes [2][ks*R/8][2R][8],
 // rows in block order: row m' = 256 mt + i is filter channel 128 mt + i (i < 128) or gate channel 128 mt + i - 128
+template <bool BF>
 __global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int ks, int R, int ldw, float scale,
                                    const float* __restrict__ scale_dev) {
     scale *= dev_scale(scale_dev);
@@ -146,12 +154,13 @@ __global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = w[((size_t)j * R + c0 + e) * ldw + col] * scale;
     uint4 p0, p1;
-    split8(v, p0, p1);
+    split8<BF>(v, p0, p1);
     planes[(size_t)kc * M + mp] = p0;
-    planes[((size_t)KC + kc) * M + mp] = p1;
+    if (!BF) planes[((size_t)KC + kc) * M + mp] = p1;
 }
 
 // w [K][ldw] fp32 (columns = output rows m) -> planes [2][K/8][M][8], natural row order
+template <bool BF>
 __global__ void pack_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int K, int M, int ldw, float scale,
                               const float* __restrict__ scale_dev) {
     scale *= dev_scale(scale_dev);
@@ -165,9 +174,9 @@ __global__ void pack_w_kernel(const float* __restrict__ w, uint4* __restrict__ p
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = w[(size_t)(kc * 8 + e) * ldw + m] * scale;
     uint4 p0, p1;
-    split8(v, p0, p1);
+    split8<BF>(v, p0, p1);
     planes[(size_t)kc * M + m] = p0;
-    planes[((size_t)KC + kc) * M + m] = p1;
+    if (!BF) planes[((size_t)KC + kc) * M + m] = p1;
 }
 
 struct GateArgs {
@@ -194,7 +203,9 @@ struct LoopGeom {
 
 // acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: 16 accumulator tiles per wave, operands through
 // VGPRs into the 4-stage LDS ring, fragments double-buffered in registers, one barrier per step.
+template <bool BF>
 __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, const LoopGeom& g, int wv, int lane) {
+    constexpr int NP = BF ? 1 : 2;        // planes per operand; a wave moves 2 * NP weight and 2 * NP activation pieces per step
     const int l31 = lane & 31, lhi = lane >> 5;
     const int KCA = g.ks * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
     const int nsteps = g.ks * spt;
@@ -202,10 +213,11 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(g.xp, (unsigned)((size_t)2 * g.xKC * g.NB * 16));
     // Stage image: 16 weight pieces (tile i, plane p at (i * 2 + p) KiB) then 16 activation pieces.  Wave wv moves
     // pieces wv*4 .. wv*4+3 of either kind; lane = (k half, row) as the MFMA wants it.
-    int voffA[4], voffB[4], trow[4];
+    int voffA[2 * NP], voffB[2 * NP], trow[2 * NP], piece[2 * NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wv * 4 + i, tile = q >> 1, p = q & 1;
+    for (int i = 0; i < 2 * NP; ++i) {
+        const int q = wv * 2 * NP + i, tile = q / NP, p = q % NP;
+        piece[i] = tile * 2 + p;
         voffA[i] = ((p * KCA + lhi) * g.M + g.m_row0 + tile * 32 + l31) * 16;
         voffB[i] = ((p * g.xKC + g.xkc0 + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
         trow[i] = g.t0 + tile * 32 + l31;                    // time of this lane's activation row
@@ -213,24 +225,24 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     // Software pipeline of one step s (one barrier): the MFMAs run on the fragments of stage s, which were read from
     // LDS during step s - 1; meanwhile the fragments of stage s + 1 are read into the other fragment set; behind the
     // MFMAs stage s + 2 (requested from global memory one step ago) is written to LDS and stage s + 3 is requested.
-    f32x4 rg[PIECES];
+    f32x4 rg[4 * NP];
     auto rissue = [&](int s) {
         const int j = s / spt, kc = (s - j * spt) * 2;
         const int shift = (g.ks - 1 - j) * g.dilation * (g.dir < 0 ? -1 : 1);   // rows before / behind the batch row read as zero
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * NP; ++i) {
             rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * g.M * 16, 0);
             const int tr = trow[i] - shift;
             const int vb = (tr >= 0 && tr < g.T) ? voffB[i] + (kc * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
-            rg[4 + i] = vqw_buf_load4(rb, vb, 0);
+            rg[2 * NP + i] = vqw_buf_load4(rb, vb, 0);
         }
     };
     auto rcommit = [&](int s) {
-        char* dst = smem + (s % NSTG) * STG_BYTES + wv * 4 * 1024 + lane * 16;
+        char* dst = smem + (s % NSTG) * STG_BYTES + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(dst + i * 1024) = rg[i];
-            *reinterpret_cast<f32x4*>(dst + 16 * 1024 + i * 1024) = rg[4 + i];
+        for (int i = 0; i < 2 * NP; ++i) {
+            *reinterpret_cast<f32x4*>(dst + piece[i] * 1024) = rg[i];
+            *reinterpret_cast<f32x4*>(dst + 16 * 1024 + piece[i] * 1024) = rg[2 * NP + i];
         }
     };
     struct Frags { uint4 a[8][2], b[2][2]; };
@@ -239,11 +251,11 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) f.a[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
+            for (int p = 0; p < NP; ++p) f.a[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) f.b[j][p] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + p) * 1024);
+            for (int p = 0; p < NP; ++p) f.b[j][p] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + p) * 1024);
     };
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -265,6 +277,10 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {   // small terms first
+                if (BF) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[i][0]), __builtin_bit_cast(bf16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
+                    continue;
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][0]), __builtin_bit_cast(f16x8, cur.b[j][1]), acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][1]), __builtin_bit_cast(f16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][0]), __builtin_bit_cast(f16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
@@ -280,20 +296,23 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
 
 // Four consecutive channels (rows 4 lhi .. 4 lhi + 3 of chunk kc) of one (batch, time) row as the lane's 8-byte
 // half of the 16-byte plane entries: the 64 lanes of a wave cover 32 rows x 16 bytes = 512 contiguous bytes per plane.
+template <bool BF>
 __device__ __forceinline__ void store_plane_quad(void* planes, int KC, int NB, int kc, int row, int lhi, const float (&x)[4], float scale = 1.0f) {
     u16 h1[4], h2[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float xs = x[e] * scale;
+        if (BF) { h1[e] = bf16_bits(xs); h2[e] = 0; continue; }
         const _Float16 a = (_Float16)xs;
         h1[e] = f16_bits(a);
         h2[e] = f16_bits((_Float16)(xs - (float)a));
     }
     char* base = reinterpret_cast<char*>(planes) + ((size_t)kc * NB + row) * 16 + lhi * 8;
     *reinterpret_cast<uint2*>(base) = make_uint2(h1[0] | ((unsigned)h1[1] << 16), h1[2] | ((unsigned)h1[3] << 16));
-    *reinterpret_cast<uint2*>(base + (size_t)KC * NB * 16) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
+    if (!BF) *reinterpret_cast<uint2*>(base + (size_t)KC * NB * 16) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_gate_desc& d = a.d;
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
         g.wp = d.wp; g.xp = d.xp; g.M = 2 * R; g.Cin = R; g.ks = d.ks; g.dilation = d.dilation; g.NB = a.NB;
         g.xKC = R / 8; g.xkc0 = 0; g.dir = 1; g.T = T;
         g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
-        f16x3_mainloop(acc, smem, g, wv, lane);
+        f16x3_mainloop<BF>(acc, smem, g, wv, lane);
     }
 
     // ---- epilogue: + bias + upsampled condition (add_condition, wavenet_ops.py:93-101), tanh(filter) * sigmoid(gate).
@@ -359,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
             if (d.out_planes) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    store_plane_quad(d.out_planes, d.out_planes_KC > 0 ? d.out_planes_KC : R / 8, a.NB, d.out_planes_kc0 + 16 * mt + 4 * i + v4,
+                    store_plane_quad<BF>(d.out_planes, d.out_planes_KC > 0 ? d.out_planes_KC : R / 8, a.NB, d.out_planes_kc0 + 16 * mt + 4 * i + v4,
                                      n0 + 64 * wv + 32 * j + l31, lhi, gq[j]);
             }
         }
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
 
 // The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
 // rows 0..S-1: skip += W_s g + b_s; rows S..S+R-1: net' = net + W_r g + b_r (and net' as planes for the next gate conv).
+template <bool BF>
 __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
         g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = Cin; g.ks = d.ks > 0 ? d.ks : 1; g.dilation = d.dilation > 0 ? d.dilation : 1; g.NB = a.NB;
         g.xKC = d.xp_KC > 0 ? d.xp_KC : Cin / 8; g.xkc0 = d.xp_kc0; g.dir = d.dir < 0 ? -1 : 1; g.T = T;
         g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
-        f16x3_mainloop(acc, smem, g, wv, lane);
+        f16x3_mainloop<BF>(acc, smem, g, wv, lane);
     }
     const bool is_skip = mt * 256 < S;    // 256 | S: a block is all skip rows or all residual rows
     const bool hb = d.bias != nullptr;
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
                 for (int j = 0; j < 2; ++j) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { gmax = fmaxf(gmax, fabsf(nq[j][e])); gbad |= !(fabsf(nq[j][e]) <= 3.0e38f); }
-                    store_plane_quad(d.net_out_planes, d.planes_KC > 0 ? d.planes_KC : R / 8, a.NB, d.planes_kc0 + (m0 - S) / 8,
+                    store_plane_quad<BF>(d.net_out_planes, d.planes_KC > 0 ? d.planes_KC : R / 8, a.NB, d.planes_kc0 + (m0 - S) / 8,
                                      n0 + 64 * wv + 32 * j + l31, lhi, nq[j], ps);
                 }
             }
@@ -433,6 +453,7 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
 // Gate backward (the transpose of gated_cnn's tanh * sigmoid, wavenet_ops.py:112-113, behind the transposed 1x1 convs):
 // dg = W_out^T [dskip; dnet] over the gradient planes (dskip in chunks 0..S/8-1, dnet behind it), then
 // dpre[filter c] = dg * sg * (1 - th^2), dpre[gate c] = dg * th * sg * (1 - sg); dpre also as planes for the input gradient.
+template <bool BF>
 __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a)
         g.wp = d.wp; g.xp = d.xp; g.M = R; g.Cin = d.Cin; g.ks = 1; g.dilation = 1; g.NB = a.NB;
         g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
         g.xKC = d.xp_KC > 0 ? d.xp_KC : d.Cin / 8; g.xkc0 = d.xp_kc0; g.dir = 1; g.T = T;
-        f16x3_mainloop(acc, smem, g, wv, lane);
+        f16x3_mainloop<BF>(acc, smem, g, wv, lane);
     }
     const int tcol = t0 + 64 * wv + l31;
     const float ps = (d.plane_scale > 0.0f ? d.plane_scale : 1.0f) * dev_scale(d.out_scale);
@@ -487,8 +508,8 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a)
             if (d.net_out_planes) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    store_plane_quad(d.net_out_planes, PKC, a.NB, d.planes_kc0 + c0 / 8, n0 + 64 * wv + 32 * j + l31, lhi, qf[j], ps);
-                    store_plane_quad(d.net_out_planes, PKC, a.NB, d.planes_kc0 + (R + c0) / 8, n0 + 64 * wv + 32 * j + l31, lhi, qg[j], ps);
+                    store_plane_quad<BF>(d.net_out_planes, PKC, a.NB, d.planes_kc0 + c0 / 8, n0 + 64 * wv + 32 * j + l31, lhi, qf[j], ps);
+                    store_plane_quad<BF>(d.net_out_planes, PKC, a.NB, d.planes_kc0 + (R + c0) / 8, n0 + 64 * wv + 32 * j + l31, lhi, qg[j], ps);
                 }
             }
         }
@@ -527,11 +548,13 @@ struct WgArgs {
     int total_o0, total_o1;   // q_total covers columns [total_o0, total_o1) only (e.g. the residual rows S..S+R)
 };
 
+template <bool BF>
 __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
     u16 a[4], b[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float xs = v[e] * sc;
+        if (BF) { a[e] = bf16_bits(xs); b[e] = 0; continue; }
         const _Float16 h1 = (_Float16)xs;
         a[e] = f16_bits(h1);
         b[e] = f16_bits((_Float16)(xs - (float)h1));
@@ -541,7 +564,7 @@ __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
 }
 
 // ODD: some tap shift is not a multiple of 4 (compile-time: a branch would cut the loop body into scheduling regions)
-template <bool ODD>
+template <bool ODD, bool BF>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -593,12 +616,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         const int g = wv * 2 + (n >> 2), nn = n & 3;
         char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STG_BYTES + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
         uint2 lo;
-        uint2 hi = split4(rgp[n], scp, lo);
+        uint2 hi = split4<BF>(rgp[n], scp, lo);
         *reinterpret_cast<uint2*>(st + (g * 2 + 0) * 1024) = hi;
-        *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
-        hi = split4(rgq[n], scq, lo);
+        if (!BF) *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
+        hi = split4<BF>(rgq[n], scq, lo);
         *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 0) * 1024) = hi;
-        *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
+        if (!BF) *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
     };
     // q sums (bias / condition gradients): the thread's two q rows (groups wv*2 and wv*2+1), its half of the 32 steps
     const bool do_sum = mt == 0 && (a.q_seg != nullptr || (a.q_total != nullptr && o0 < a.total_o1 && o0 + 256 > a.total_o0));
@@ -627,14 +650,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     auto read_a = [&](int i, int stage) {
         const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16;
         fa[i][0] = *reinterpret_cast<const uint4*>(st + (i * 2 + 0) * 1024);
-        fa[i][1] = *reinterpret_cast<const uint4*>(st + (i * 2 + 1) * 1024);
+        if (!BF) fa[i][1] = *reinterpret_cast<const uint4*>(st + (i * 2 + 1) * 1024);
     };
     auto read_b = [&](uint4 (&b)[2][2], int stage) {
         const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16 + 16 * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) b[j][pl] = *reinterpret_cast<const uint4*>(st + ((wv * 2 + j) * 2 + pl) * 1024);
+            for (int pl = 0; pl < (BF ? 1 : 2); ++pl) b[j][pl] = *reinterpret_cast<const uint4*>(st + ((wv * 2 + j) * 2 + pl) * 1024);
     };
     f32x16 acc[8][2];
 #pragma unroll
@@ -646,6 +669,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     auto mfma_row = [&](int i, const uint4 (&b)[2][2]) {       // 6 MFMAs: row tile i x this wave's 2 column tiles, small terms first
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            if (BF) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][0]), __builtin_bit_cast(bf16x8, b[j][0]), acc[i][j], 0, 0, 0);
+                continue;
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, b[j][1]), acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][1]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
@@ -783,35 +810,40 @@ int vqw_f16x3_update_scales(uint32_t* amax, float* scale, int n, int target_exp,
 }
 
 int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC,
-                                const float* scale_dev, uint32_t* amax, int32_t* flag, vqw_stream_t s_) {
+                                const float* scale_dev, uint32_t* amax, int32_t* flag, int mode, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(x && planes, "vqw_f16x3_split_activations: null pointer");
     VQW_CHECK(B > 0 && T > 0 && C > 0 && C % 8 == 0, "vqw_f16x3_split_activations: C must be a positive multiple of 8 (got %d)", C);
     if (KC <= 0) { KC = C / 8; kc0 = 0; }
     VQW_CHECK(kc0 >= 0 && kc0 + C / 8 <= KC, "vqw_f16x3_split_activations: bad chunk range (kc0=%d KC=%d)", kc0, KC);
     const size_t n = (size_t)B * T * (C / 8);
-    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
-                       scale_dev, amax, flag);
+    VQW_CHECK(mode == 0 || mode == 1, "vqw_f16x3_split_activations: mode must be 0 (two fp16 planes) or 1 (one bf16 plane)");
+    if (mode) hipLaunchKernelGGL(split_act_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
+                                 scale_dev, amax, flag);
+    else hipLaunchKernelGGL(split_act_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
+                            scale_dev, amax, flag);
     VQW_LAUNCH_CHECK("vqw_f16x3_split_activations");
     return 0;
 }
 
-int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count, const float* scale_dev, vqw_stream_t s_) {
+int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int ldw, float scale, int count, const float* scale_dev, int mode, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(w && planes, "vqw_f16x3_pack_gate_weights: null pointer");
     VQW_CHECK(ks >= 1 && R > 0 && R % 128 == 0 && ldw >= 2 * R && count >= 1 && count <= 65535, "vqw_f16x3_pack_gate_weights: needs R %% 128 == 0, ldw >= 2R, 1 <= count <= 65535 (R=%d ldw=%d count=%d)", R, ldw, count);
     const int n = (ks * R / 8) * 2 * R;
-    hipLaunchKernelGGL(pack_gate_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev);
+    if (mode) hipLaunchKernelGGL(pack_gate_w_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev);
+    else hipLaunchKernelGGL(pack_gate_w_kernel<false>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_gate_weights");
     return 0;
 }
 
-int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count, const float* scale_dev, vqw_stream_t s_) {
+int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count, const float* scale_dev, int mode, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(w && planes, "vqw_f16x3_pack_weights: null pointer");
     VQW_CHECK(K > 0 && K % 8 == 0 && M > 0 && ldw >= M && count >= 1 && count <= 65535, "vqw_f16x3_pack_weights: needs K %% 8 == 0, ldw >= M, 1 <= count <= 65535 (K=%d M=%d ldw=%d count=%d)", K, M, ldw, count);
     const int n = (K / 8) * M;
-    hipLaunchKernelGGL(pack_w_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
+    if (mode) hipLaunchKernelGGL(pack_w_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
+    else hipLaunchKernelGGL(pack_w_kernel<false>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_weights");
     return 0;
 }
@@ -832,18 +864,24 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     OutArgs a;
     a.d = d;
     a.NB = d.B * d.T;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(out_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+    VQW_CHECK(d.mode == 0 || d.mode == 1, "vqw_f16x3_out_conv: mode must be 0 (fp16x3) or 1 (bf16)");
+    const bool bf = d.mode == 1;
+    const void* kout = bf ? reinterpret_cast<const void*>(out_f16x3_kernel<true>) : reinterpret_cast<const void*>(out_f16x3_kernel<false>);
+    const void* kbwd = bf ? reinterpret_cast<const void*>(gate_bwd_f16x3_kernel<true>) : reinterpret_cast<const void*>(gate_bwd_f16x3_kernel<false>);
+    if (hipFuncSetAttribute(kout, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
     if (d.epi == 1) {   // gate backward
         VQW_CHECK(d.S == 0 && d.R > 0 && d.aux0 && d.aux1 && d.Cin > 0, "vqw_f16x3_out_conv: gate backward needs S = 0, saved tanh (aux0) and sigmoid (aux1), Cin");
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gate_bwd_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
             return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-        hipLaunchKernelGGL(gate_bwd_f16x3_kernel, dim3((d.R / 256) * (a.NB / 256)), dim3(256), NSTG * STG_BYTES, st, a);
+        if (bf) hipLaunchKernelGGL(gate_bwd_f16x3_kernel<true>, dim3((d.R / 256) * (a.NB / 256)), dim3(256), NSTG * STG_BYTES, st, a);
+        else hipLaunchKernelGGL(gate_bwd_f16x3_kernel<false>, dim3((d.R / 256) * (a.NB / 256)), dim3(256), NSTG * STG_BYTES, st, a);
         VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");
         return 0;
     }
     const int blocks = ((d.S + d.R) / 256) * (a.NB / 256);
-    hipLaunchKernelGGL(out_f16x3_kernel, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    if (bf) hipLaunchKernelGGL(out_f16x3_kernel<true>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    else hipLaunchKernelGGL(out_f16x3_kernel<false>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");
     return 0;
 }
@@ -870,10 +908,14 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
                   "vqw_f16x3_gate_conv: T / cond_T must be a multiple of 32 (T=%d cond_T=%d)", d.T, d.cond_T);
         a.ratio = d.T / d.cond_T;
     }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gate_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+    VQW_CHECK(d.mode == 0 || d.mode == 1, "vqw_f16x3_gate_conv: mode must be 0 (fp16x3) or 1 (bf16)");
+    const bool bf = d.mode == 1;
+    if (hipFuncSetAttribute(bf ? reinterpret_cast<const void*>(gate_f16x3_kernel<true>) : reinterpret_cast<const void*>(gate_f16x3_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_gate_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
     const int blocks = (d.R / 128) * (a.NB / 256);
-    hipLaunchKernelGGL(gate_f16x3_kernel, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    if (bf) hipLaunchKernelGGL(gate_f16x3_kernel<true>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    else hipLaunchKernelGGL(gate_f16x3_kernel<false>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_gate_conv");
     return 0;
 }
@@ -917,11 +959,14 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     VQW_CHECK((size_t)tiles * nsplit * 65536 <= (size_t)d.slab_floats, "vqw_f16x3_wgrad: slab too small (%d tiles x %d splits x 65536 floats)", tiles, nsplit);
     bool odd = false;
     for (int j = 0; j < d.ntaps; ++j) odd |= (d.tap_shift[j] & 3) != 0;
-    const void* kfn = odd ? reinterpret_cast<const void*>(wgrad_f16x3_kernel<true>) : reinterpret_cast<const void*>(wgrad_f16x3_kernel<false>);
-    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
+    VQW_CHECK(d.mode == 0 || d.mode == 1, "vqw_f16x3_wgrad: mode must be 0 (fp16x3) or 1 (bf16)");
+    typedef void (*kfn_t)(WgArgs);
+    const kfn_t ktab[4] = {wgrad_f16x3_kernel<false, false>, wgrad_f16x3_kernel<true, false>, wgrad_f16x3_kernel<false, true>,
+                           wgrad_f16x3_kernel<true, true>};
+    const kfn_t kfn = ktab[(odd ? 1 : 0) + 2 * d.mode];
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-    if (odd) hipLaunchKernelGGL(wgrad_f16x3_kernel<true>, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
-    else hipLaunchKernelGGL(wgrad_f16x3_kernel<false>, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
+    hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
     const long tap_stride = d.dw_tap_stride > 0 ? (long)d.dw_tap_stride : (long)d.Cp * lddw;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(65536 / 4 / 256, tiles), dim3(256), 0, st, d.slab, d.dw, nsplit, a.n_nt, d.Cp / 256, d.Cp,
                        (long)lddw, tap_stride);

@@ -229,32 +229,32 @@ def f16x3_update_scales(amax, scale, *, target_exp, reset=True, flag=None):
     L.check(L.lib().vqw_f16x3_update_scales(L.ptr(amax), L.ptr(scale), n, target_exp, int(reset), _slot(flag, 'flag', torch.int32), L.stream()))
 
 
-def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_dev=None, amax=None, flag=None):
+def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_dev=None, amax=None, flag=None, mode=0):
     """scale * scale_dev * x [B][C][T] fp32 -> planes [2][KC or C/8][B*T][8] fp16, chunks kc0..."""
     _need(x, B * Cc * T, 'x')
     _need_planes(planes, 2 * B * T * (KC * 8 if KC else Cc), 'planes')
     L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, float(scale), kc0, KC, _slot(scale_dev, 'scale_dev'),
-                                                _slot(amax, 'amax', torch.int32), _slot(flag, 'flag', torch.int32), L.stream()))
+                                                _slot(amax, 'amax', torch.int32), _slot(flag, 'flag', torch.int32), mode, L.stream()))
 
 
-def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1, scale_dev=None):
+def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1, scale_dev=None, mode=0):
     """`count` layers back to back in `w` ([count][ks][R][ldw]) and in `planes`."""
     _need(w, (count - 1) * ks * R * ldw + (ks * R - 1) * ldw + 2 * R, 'w')
     _need_planes(planes, count * 2 * ks * R * 2 * R, 'planes')
-    L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), L.stream()))
+    L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), mode, L.stream()))
 
 
-def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None):
+def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mode=0):
     """w [count][K][ldw] fp32 -> planes [count][2][K/8][M][8] fp16 of scale * scale_dev * w."""
     _need(w, (count - 1) * Kd * ldw + (Kd - 1) * ldw + M, 'w')
     _need_planes(planes, count * 2 * Kd * M, 'planes')
-    L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), L.stream()))
+    L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), mode, L.stream()))
 
 
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
                    net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
                    planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None, x_scale=None, w_scale=None,
-                   out_scale=None, out_amax=None, flag=None):
+                   out_scale=None, out_amax=None, flag=None, mode=0):
     cin = Cin if Cin > 0 else R
     kc_all = xp_KC if xp_KC > 0 else cin // 8
     _need_planes(xp, 2 * kc_all * 8 * B * T, 'xp')
@@ -288,12 +288,13 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     d.w_scale_inv = float(w_scale_inv)
     d.x_scale, d.w_scale, d.out_scale = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale'), _slot(out_scale, 'out_scale')
     d.out_amax, d.flag = _slot(out_amax, 'out_amax', torch.int32), _slot(flag, 'flag', torch.int32)
+    d.mode = mode
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 
 
 def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,
                     cond_bstride=0, save0=None, save1=None, out_planes=None, out_planes_kc0=0, out_planes_KC=0, x_scale=None,
-                    w_scale=None):
+                    w_scale=None, mode=0):
     _need_planes(xp, 2 * B * R * T, 'xp')
     _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
     _need(out0, B * R * T, 'out0')
@@ -321,11 +322,12 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     d.B, d.T, d.R, d.ks, d.dilation, d.cond_T = B, T, R, ks, dilation, cond_T
     d.w_scale_inv = float(w_scale_inv)
     d.x_scale, d.w_scale = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale')
+    d.mode = mode
     L.check(L.lib().vqw_f16x3_gate_conv(C.byref(d), L.stream()))
 
 
 def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
-                q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0):
+                q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=0):
     """vqw_f16x3_wgrad: dw[j][c][o] += sum_{b,t} p[b][c][t+taps[j]] * q[b][o][t] on the fp16x3 engine (slab = scratch)."""
     lddw = (Q0 + Q1) if lddw is None else lddw
     dw_tap_stride = Cp * lddw if dw_tap_stride is None else dw_tap_stride
@@ -342,7 +344,7 @@ def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None
     d.B, d.T, d.Cp, d.Q0, d.Q1, d.ntaps = B, T, Cp, Q0, Q1, len(taps)
     for j, sh in enumerate(taps):
         d.tap_shift[j] = int(sh)
-    d.lddw, d.nsplit, d.dw_tap_stride = lddw, nsplit, dw_tap_stride
+    d.lddw, d.nsplit, d.dw_tap_stride, d.mode = lddw, nsplit, dw_tap_stride, mode
     if q_total is not None:      # q_total[o] += sum_{b,t} q[b][o][t] for o in total_cols = (o0, o1)
         o0, o1 = total_cols if total_cols is not None else (0, Q0 + Q1)
         _need(q_total, o1, 'q_total')

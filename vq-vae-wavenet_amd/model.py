@@ -94,8 +94,13 @@ class VQVAE:
         if engine not in ('fp32', 'f16x3'):
             raise ValueError("VQW_ENGINE must be 'fp32' or 'f16x3' (got %r)" % engine)
         ladder = os.environ.get('VQW_GATE_F16X3', '0')
-        self.x3_guard = engine == 'f16x3' and ladder == '0'
-        if self.x3_guard:
+        # VQW_DTYPE=bf16 (BASELINE.json configs[4]: bf16 storage + fp32 accumulate): the same kernels with ONE bf16 plane per
+        # operand and one bf16 MFMA per product; master weights, optimiser state and the residual stream stay fp32
+        self.bf16 = os.environ.get('VQW_DTYPE', model_cfg.get('dtype', 'f32')) == 'bf16'
+        self.x3_mode = 1 if self.bf16 else 0
+        self.x3_guard = engine == 'f16x3' and ladder == '0' and not self.bf16
+        self.x3_all = self.x3_guard or self.bf16          # the plane engine carries every decoder contraction, or none
+        if self.x3_all:
             ladder = '5'
         self.gate_f16x3 = ladder in ('1', '2', '3', '4', '5')
         self.out_f16x3 = ladder in ('2', '3', '4', '5')
@@ -446,9 +451,10 @@ class VQVAE:
         f16x3 = self.gate_f16x3 and T % 256 == 0 and R % 128 == 0 and (T // Tz) % 32 == 0
         f16x3_skip = f16x3 and self.skip_f16x3 and R % 256 == 0 and S % 256 == 0 and 2 * L * R * B * T * 2 < (1 << 31)
         f16x3_out = f16x3 and self.out_f16x3 and R % 256 == 0 and S % 256 == 0    # the 1x1 skip + residual conv too; it hands the next layer its planes
-        if self.x3_guard and not (f16x3_skip and self._x3_active):   # guarded engine: all of it or none of it
+        if self.x3_all and not (f16x3_skip and self._x3_active):   # guarded / bf16 engine: all of it or none of it
             f16x3 = f16x3_skip = f16x3_out = False
-        ws['x3_used'] = bool(f16x3_skip and self.x3_guard)
+        ws['x3_used'] = bool(f16x3_skip and self.x3_all)
+        md = self.x3_mode
         gd = self.x3_guard and f16x3_skip
         sc = (lambda name, i=0: self.x3_scale[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
         am = (lambda name, i=0: self.x3_amax[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
@@ -462,30 +468,30 @@ class VQVAE:
             K.f16x3_update_scales(self.x3_amax[:2], self.x3_scale[:2], target_exp=14, flag=flag)
             K.f16x3_update_scales(am('X', 0), sc('X', 0), target_exp=13, flag=flag)
         if f16x3:      # this step's weights of all layers as fp16 planes, one launch per kind
-            K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, WS, count=L, scale_dev=sc('WG'))
+            K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, WS, count=L, scale_dev=sc('WG'), mode=md)
             if f16x3_skip:     # [L*R][S] skip kernels of all layers as one K = L*R operand; the residual kernels per layer
-                K.f16x3_pack_weights(P['out_w'], ws['wskip'], L * R, S, S + R, WS, scale_dev=sc('WO'))
-                K.f16x3_pack_weights(P['out_w'].view(-1)[S:], ws['wres'], R, R, S + R, WS, count=L, scale_dev=sc('WO'))
+                K.f16x3_pack_weights(P['out_w'], ws['wskip'], L * R, S, S + R, WS, scale_dev=sc('WO'), mode=md)
+                K.f16x3_pack_weights(P['out_w'].view(-1)[S:], ws['wres'], R, R, S + R, WS, count=L, scale_dev=sc('WO'), mode=md)
             elif f16x3_out:
-                K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, WS, count=L)
+                K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, WS, count=L, mode=md)
         for l, d in enumerate(self.dil):
             if f16x3:
                 if l == 0 or not f16x3_out:
-                    K.f16x3_split_activations(net[l], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag)
+                    K.f16x3_split_activations(net[l], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
                 K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if save else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
                                   cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T=T, R=R, ks=self.ks,
                                   dilation=d, w_scale_inv=1.0 / WS, out_planes=ws['gp'] if f16x3_out else None,
                                   out_planes_kc0=l * (R // 8) if f16x3_skip else 0, out_planes_KC=L * (R // 8) if f16x3_skip else 0,
-                                  x_scale=sc('X', l), w_scale=sc('WG'))
+                                  x_scale=sc('X', l), w_scale=sc('WG'), mode=md)
                 if f16x3_skip:   # residual half now; the skip half of all layers after the loop
                     K.f16x3_out_conv(xp=ws['gp'], xp_kc0=l * (R // 8), xp_KC=L * (R // 8), Cin=R, wp=ws['wres'][l],
                                      bias=P['out_b'][l][S:], net_in=net[l], net_out=net[l + 1], net_out_planes=ws['xp'],
                                      B=B, T=T, R=R, S=0, w_scale_inv=1.0 / WS, w_scale=sc('WO'), out_scale=sc('X', l + 1),
-                                     out_amax=am('X', l + 1), flag=flag)
+                                     out_amax=am('X', l + 1), flag=flag, mode=md)
                 elif f16x3_out:
                     K.f16x3_out_conv(xp=ws['gp'], wp=ws['wop'][l], bias=P['out_b'][l], skip=ws['skip'], net_in=net[l],
-                                     net_out=net[l + 1], net_out_planes=ws['xp'], B=B, T=T, R=R, S=S, w_scale_inv=1.0 / 256.0)
+                                     net_out=net[l + 1], net_out_planes=ws['xp'], B=B, T=T, R=R, S=S, w_scale_inv=1.0 / 256.0, mode=md)
                 else:
                     K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
                                 aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
@@ -501,7 +507,7 @@ class VQVAE:
                         epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])                                       # :132-136, wavenet.py:72-73
         if f16x3_skip:   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
             K.f16x3_out_conv(xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
-                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / WS, w_scale=sc('WO'))
+                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / WS, w_scale=sc('WO'), mode=md)
         K.conv_gemm(x0=ws['skip'], in_relu=True, w=P['post1_w'], bias=P['post1_b'], out0=ws['h1'],
                     cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T, M=S,
                     C0=S, taps=[0])                                                       # wavenet.py:80-88
@@ -588,8 +594,10 @@ class VQVAE:
         # gradient operand is lifted by 2^20 before it is split into fp16 planes (|dpre| < 0.06 assumed, not checked).
         dgrad_x3 = self.dgrad_f16x3 and T % 256 == 0 and R % 256 == 0
         gbwd_x3 = dgrad_x3 and self.gbwd_f16x3 and S % 256 == 0
-        gd = bool(ws.get('x3_used'))
-        if self.x3_guard and not gd:
+        full = bool(ws.get('x3_used'))
+        gd = full and self.x3_guard
+        md = self.x3_mode
+        if self.x3_all and not full:
             dgrad_x3 = gbwd_x3 = False
         calib = self.x3_guard and not self._x3_active     # fp32 repeat of a step: measure what the planes would have held
         sc = (lambda name, i=0: self.x3_scale[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
@@ -597,16 +605,16 @@ class VQVAE:
         flag = self.x3_flag if gd else None
         GS = 1.0 if gd else float(2 ** 20)      # guarded: the gradient scales live on the device
         WS = 1.0 if gd else 256.0
-        wg_x3 = gd and gbwd_x3 and T % 32 == 0 and os.environ.get('VQW_WGRAD_X3', '1') != '0'
+        wg_x3 = full and gbwd_x3 and T % 32 == 0 and os.environ.get('VQW_WGRAD_X3', '1') != '0'
         if wg_x3 and 'wslab' not in ws:
             ws['wslab'] = torch.empty(256 * 65536, device=self.dev)      # partial 256x256 tiles of one launch (tiles x K splits <= CUs)
         if dgrad_x3:
-            K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, WS, count=L, scale_dev=sc('WG'))
+            K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, WS, count=L, scale_dev=sc('WG'), mode=md)
         if gbwd_x3:
-            K.f16x3_pack_weights(Tt['out_w'], ws['wgb'], S + R, R, R, WS, count=L, scale_dev=sc('WO'))
-            K.f16x3_pack_weights(Tt['out_w'][L - 1], ws['wgb_top'], S, R, R, WS, scale_dev=sc('WO'))       # the top layer has no dnet
+            K.f16x3_pack_weights(Tt['out_w'], ws['wgb'], S + R, R, R, WS, count=L, scale_dev=sc('WO'), mode=md)
+            K.f16x3_pack_weights(Tt['out_w'][L - 1], ws['wgb_top'], S, R, R, WS, scale_dev=sc('WO'), mode=md)       # the top layer has no dnet
             K.f16x3_split_activations(dskip, ws['gr'], B, S, T, scale=GS, kc0=0, KC=(S + R) // 8, scale_dev=sc('G'),
-                                      amax=am('G'), flag=flag)   # one tensor for all layers
+                                      amax=am('G'), flag=flag, mode=md)   # one tensor for all layers
         if calib:
             K.f16x3_amax(dskip, am('G'))
         if wg_x3:      # the weight-gradient kernels add the per-frame sums of dpre into the condition gradient
@@ -624,7 +632,7 @@ class VQVAE:
                 K.f16x3_out_conv(epi=1, xp=ws['gr'], Cin=S if top else S + R, xp_KC=(S + R) // 8,
                                  wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=ws['th'][l], aux1=ws['sg'][l], net_out=dpre,
                                  net_out_planes=ws['dp'], plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (WS * GS),
-                                 x_scale=sc('G'), w_scale=sc('WO'), out_scale=sc('DP', l), out_amax=am('DP', l), flag=flag)
+                                 x_scale=sc('G'), w_scale=sc('WO'), out_scale=sc('DP', l), out_amax=am('DP', l), flag=flag, mode=md)
             else:
                 K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
                             aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
@@ -637,13 +645,13 @@ class VQVAE:
             taps_b = [(ks - 1 - j) * d for j in range(ks)]
             if dgrad_x3:
                 if not gbwd_x3:      # (gate backward hands dpre over as planes)
-                    K.f16x3_split_activations(dpre, ws['dp'], B, 2 * R, T, scale=GS)
+                    K.f16x3_split_activations(dpre, ws['dp'], B, 2 * R, T, scale=GS, mode=md)
                 K.f16x3_out_conv(xp=ws['dp'], Cin=2 * R, ks=ks, dilation=d, direction=-1, wp=ws['wdg'][l],
                                  net_in=None if top else dnet, net_out=dnet_next, B=B, T=T, R=R, S=0,
                                  w_scale_inv=1.0 / (WS * GS),
                                  net_out_planes=ws['gr'] if gbwd_x3 else None, planes_kc0=S // 8 if gbwd_x3 else 0,
                                  planes_KC=(S + R) // 8 if gbwd_x3 else 0, plane_scale=GS if gbwd_x3 else 0.0,
-                                 x_scale=sc('DP', l), w_scale=sc('WG'), out_scale=sc('G'), out_amax=am('G'), flag=flag)
+                                 x_scale=sc('DP', l), w_scale=sc('WG'), out_scale=sc('G'), out_amax=am('G'), flag=flag, mode=md)
             elif top:
                 K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
                             tile=self.tiles['dgrad'])
@@ -659,10 +667,10 @@ class VQVAE:
                     # the bias sums and the condition gradient (sums of dpre per condition frame) come out of the same kernels
                     K.f16x3_wgrad(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], slab=ws['wslab'], B=B,
                                   T=T, Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0], q0_scale=sc('G'), q1_scale=sc('G'),
-                                  q_total=None if top else G['out_b'][l], total_cols=(S, S + R))
+                                  q_total=None if top else G['out_b'][l], total_cols=(S, S + R), mode=md)
                     K.f16x3_wgrad(p=net[l], q0=dpre, dw=G['gated_w'][l], slab=ws['wslab'], B=B, T=T, Cp=R, Q0=2 * R,
                                   taps=[-(ks - 1 - j) * d for j in range(ks)], p_scale=sc('X', l), q0_scale=sc('DP', l),
-                                  q_seg=dce.view(-1)[l * 2 * R * Tz:], seg_T=Tz, seg_bstride=cbs)
+                                  q_seg=dce.view(-1)[l * 2 * R * Tz:], seg_T=Tz, seg_bstride=cbs, mode=md)
                 else:
                     K.wgrad_gemm(p=ws['gated'][l], q0=dskip, q1=None if top else dnet, dw=G['out_w'][l], B=B, T_q=T, T_p=T,
                                  Cp=R, Q0=S, Q1=0 if top else R, lddw=S + R, taps=[0])
@@ -785,6 +793,8 @@ class VQVAE:
         ws = self.forward(x, spk)
         self.backward(x, spk, ws)
         world = self.grad_sync.finish() if self.grad_sync is not None else 1
+        if self.bf16 and ws.get('x3_used'):
+            self.x3_steps += 1
         if self.x3_guard and ws.get('x3_used'):
             if self._x3_overflowed():
                 self.x3_fallbacks += 1
