@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""A few launches of ONE kernel of the fp16x3 engine at the benchmark shape, for rocprofv3 --pmc passes.
+usage: x3_one.py <gate|wgrad> [dilation]"""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module('vq-vae-wavenet_amd')
+K = pkg.kernels
+what = sys.argv[1]
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+B, T, R, ks = 8, 6656, 256, 3
+dev = 'cuda'
+torch.manual_seed(0)
+net, dpre = torch.randn(B, R, T, device=dev), torch.randn(B, 2 * R, T, device=dev) * 1e-5
+gw = torch.randn(ks, R, 2 * R, device=dev) * 0.06
+bias, cond = torch.randn(2 * R, device=dev), torch.randn(B, 2 * R, T // 64, device=dev)
+xp = torch.empty(2 * B * R * T, dtype=torch.float16, device=dev)
+gp = torch.empty(2 * B * R * T, dtype=torch.float16, device=dev)
+wp = torch.empty(2 * ks * R * 2 * R, dtype=torch.float16, device=dev)
+K.f16x3_split_activations(net, xp, B, R, T)
+K.f16x3_pack_gate_weights(gw, wp, ks, R, 2 * R, 256.0)
+out, s0, s1 = (torch.empty(B, R, T, device=dev) for _ in range(3))
+slab, dw = torch.empty(256 * 65536, device=dev), torch.zeros(ks, R, 2 * R, device=dev)
+for _ in range(5):
+    if what == 'gate':
+        K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save0=s0, save1=s1, bias=bias, cond=cond, cond_T=T // 64, B=B, T=T, R=R, ks=ks,
+                          dilation=d, w_scale_inv=1 / 256.0, out_planes=gp)
+    else:
+        K.f16x3_wgrad(p=net, q0=dpre, dw=dw, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, taps=[-2 * d, -d, 0])
+torch.cuda.synchronize()
