@@ -189,6 +189,10 @@ struct OutArgs {
     int NB;
 };
 
+#ifndef VQW_X3_PAT_MEM
+#define VQW_X3_PAT_MEM 1      // issue pattern of the conv main loop: LDS / global-memory instructions per MFMA ...
+#define VQW_X3_PAT_ALU 2      // ... and address computations per MFMA (tools/x3_bench.py: 1/2 measured best)
+#endif
 constexpr int NSTG = 4, STG_BYTES = 32 * 1024, PIECES = 8;   // per wave and stage: 4 weight + 4 activation pieces of 1 KiB
 
 // Geometry of one block's contraction: 256 weight rows from row m_row0 of planes with M rows, K = ks taps x Cin
@@ -225,8 +229,10 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     // Software pipeline of one step s (one barrier): the MFMAs run on the fragments of stage s, which were read from
     // LDS during step s - 1; meanwhile the fragments of stage s + 1 are read into the other fragment set; behind the
     // MFMAs stage s + 2 (requested from global memory one step ago) is written to LDS and stage s + 3 is requested.
-    f32x4 rg[4 * NP];
-    auto rissue = [&](int s) {
+    // Two register sets: the requests of stages s + 2 and s + 3 are both in flight while stage s is multiplied (one
+    // step of MFMAs, ~1500 cycles, is shorter than a stage's trip from L2: 32 KiB per CU at ~14 B/cycle).
+    f32x4 rgA[4 * NP], rgB[4 * NP];
+    auto rissue = [&](int s, f32x4 (&rg)[4 * NP]) {
         const int j = s / spt, kc = (s - j * spt) * 2;
         const int shift = (g.ks - 1 - j) * g.dilation * (g.dir < 0 ? -1 : 1);   // rows before / behind the batch row read as zero
 #pragma unroll
@@ -237,7 +243,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
             rg[2 * NP + i] = vqw_buf_load4(rb, vb, 0);
         }
     };
-    auto rcommit = [&](int s) {
+    auto rcommit = [&](int s, const f32x4 (&rg)[4 * NP]) {
         char* dst = smem + (s % NSTG) * STG_BYTES + lane * 16;
 #pragma unroll
         for (int i = 0; i < 2 * NP; ++i) {
@@ -245,17 +251,21 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
             *reinterpret_cast<f32x4*>(dst + 16 * 1024 + piece[i] * 1024) = rg[2 * NP + i];
         }
     };
-    struct Frags { uint4 a[8][2], b[2][2]; };
-    auto read_frags = [&](Frags& f, int s) {
+    // Fragments: ONE set of A fragments (8 row tiles x NP planes) that is refilled row tile by row tile -- right behind the six
+    // MFMAs of a row tile its fragments of the NEXT stage are fetched from LDS, a whole step before they are used -- and two
+    // sets of this wave's B fragments.
+    uint4 fa[8][NP], fb[2][NP], fbn[2][NP];
+    auto read_a = [&](int i, int s) {
         const char* st = smem + (s % NSTG) * STG_BYTES + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) f.a[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
+        for (int p = 0; p < NP; ++p) fa[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
+    };
+    auto read_b = [&](uint4 (&b)[2][NP], int s) {
+        const char* st = smem + (s % NSTG) * STG_BYTES + lane * 16 + 16 * 1024;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) f.b[j][p] = *reinterpret_cast<const uint4*>(st + 16 * 1024 + ((wv * 2 + j) * 2 + p) * 1024);
+            for (int p = 0; p < NP; ++p) b[j][p] = *reinterpret_cast<const uint4*>(st + ((wv * 2 + j) * 2 + p) * 1024);
     };
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -263,34 +273,63 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    Frags f0, f1;
-    rissue(0); rcommit(0);
-    rissue(1); rcommit(1);
-    rissue(2);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    read_frags(f0, 0);
-    auto step = [&](const Frags& cur, Frags& nxt, int s) {   // nsteps is even (Cin % 32 == 0 is checked by the callers)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage s + 1 is in LDS, every wave holds its fragments of stage s
-        if (s + 1 < nsteps) read_frags(nxt, s + 1);
+    // Two row tiles x two column tiles at a time, the three terms outermost (small terms first): an MFMA that accumulates
+    // into the same tile as its predecessor waits for that one's whole latency, so the four independent accumulators are
+    // rotated through between two terms of the same tile.
+    auto mfma_rows = [&](int i, const uint4 (&b)[2][NP]) {
+        if constexpr (BF) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int q = 0; q < 4; ++q)
+                acc[i + (q >> 1)][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i + (q >> 1)][0]), __builtin_bit_cast(bf16x8, b[q & 1][0]), acc[i + (q >> 1)][q & 1], 0, 0, 0);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {   // small terms first
-                if (BF) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[i][0]), __builtin_bit_cast(bf16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
-                    continue;
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ii = i + (q >> 1), j = q & 1;
+                    const int pa = term == 1 ? 1 : 0, pb = term == 0 ? 1 : 0;      // h1 h2, h2 h1, h1 h1
+                    acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ii][pa]), __builtin_bit_cast(f16x8, b[j][pb]), acc[ii][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][0]), __builtin_bit_cast(f16x8, cur.b[j][1]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][1]), __builtin_bit_cast(f16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur.a[i][0]), __builtin_bit_cast(f16x8, cur.b[j][0]), acc[i][j], 0, 0, 0);
-            }
-        if (s + 2 < nsteps) rcommit(s + 2);
-        if (s + 3 < nsteps) rissue(s + 3);
+        }
+    };
+
+    rissue(0, rgA); rcommit(0, rgA);
+    rissue(1, rgB); rcommit(1, rgB);
+    rissue(2, rgA);
+    if (3 < nsteps) rissue(3, rgB);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_a(i, 0);
+    read_b(fb, 0);
+    // One step s (one barrier): stage s + 1 is complete in LDS behind the barrier; the MFMAs of stage s run row tile by row
+    // tile with the LDS reads of stage s + 1 behind them; then stage s + 2 (requested two steps ago) goes to LDS and
+    // stage s + 4 is requested.  nsteps is even (Cin % 32 == 0 is checked by the callers).
+    auto step = [&](const uint4 (&bc)[2][NP], uint4 (&bn)[2][NP], int s, f32x4 (&rg)[4 * NP]) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int sn = s + 1 < nsteps ? s + 1 : s;          // (the last step re-reads its own stage: no branch in the body)
+        // No conditionals in the body (they would cut it into scheduling regions): past the last stages the commit rewrites
+        // stale registers into an LDS stage nobody reads again and the requests run past the end of the weight planes,
+        // where raw buffer loads return zero.
+        read_b(bn, sn);
+        rcommit(s + 2, rg);
+        rissue(s + 4, rg);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            mfma_rows(i, bc);
+            read_a(i, sn);
+            read_a(i + 1, sn);
+        }
+        // issue order: one MFMA, then one LDS / global-memory instruction and a few address computations in its shadow
+#pragma unroll
+        for (int k_ = 0; k_ < (BF ? 16 : 48); ++k_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100 | 0x200 | 0x020, BF ? 2 : VQW_X3_PAT_MEM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002 | 0x004, VQW_X3_PAT_ALU, 0);
+        }
     };
     for (int s = 0; s < nsteps; s += 2) {
-        step(f0, f1, s);
-        step(f1, f0, s + 1);
+        step(fb, fbn, s, rgA);
+        step(fbn, fb, s + 1, rgB);
     }
 }
 
@@ -666,16 +705,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto mfma_row = [&](int i, const uint4 (&b)[2][2]) {       // 6 MFMAs: row tile i x this wave's 2 column tiles, small terms first
+    // 12 MFMAs: row tiles i, i+1 x this wave's 2 column tiles, the three terms outermost (small first) so that two MFMAs
+    // into the same accumulator are three independent ones apart
+    auto mfma_rows = [&](int i, const uint4 (&b)[2][2]) {
+        if constexpr (BF) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (BF) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][0]), __builtin_bit_cast(bf16x8, b[j][0]), acc[i][j], 0, 0, 0);
-                continue;
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, b[j][1]), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][1]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]), __builtin_bit_cast(f16x8, b[j][0]), acc[i][j], 0, 0, 0);
+            for (int q = 0; q < 4; ++q)
+                acc[i + (q >> 1)][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i + (q >> 1)][0]), __builtin_bit_cast(bf16x8, b[q & 1][0]), acc[i + (q >> 1)][q & 1], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ii = i + (q >> 1), j = q & 1;
+                    const int pa = term == 1 ? 1 : 0, pb = term == 0 ? 1 : 0;
+                    acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ii][pa]), __builtin_bit_cast(f16x8, b[j][pb]), acc[ii][j], 0, 0, 0);
+                }
         }
     };
 
@@ -704,13 +749,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             // nobody reads again and the requests fall behind the end of the buffers, where raw buffer loads return zero --
             // branches would cut the body into scheduling regions and the MFMAs could no longer be interleaved.)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                mfma_row(i, fb);
+            for (int i = 0; i < 8; i += 2) {
+                mfma_rows(i, fb);
                 read_a(i, 2 * it + 1);
+                read_a(i + 1, 2 * it + 1);
                 commit_one(i, it + 1);
+                commit_one(i + 1, it + 1);
                 sum_one(i);
+                sum_one(i + 1);
 #pragma unroll
-                for (int k_ = 0; k_ < 6; ++k_) {          // 1 MFMA, then ~1/6 of the group's VALU / LDS work in its shadow
+                for (int k_ = 0; k_ < 12; ++k_) {         // 1 MFMA, then ~1/12 of the group's VALU / LDS work in its shadow
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200, 12, 0);
                 }
@@ -719,11 +767,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             set_pair(s_begin + it + 2);
             read_b(fb, 2 * it + 1);        // (after the first stage's last use of fb: 16 registers instead of 32)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                mfma_row(i, fb);
+            for (int i = 0; i < 8; i += 2) {
+                mfma_rows(i, fb);
                 issue_one(i);
+                issue_one(i + 1);
 #pragma unroll
-                for (int k_ = 0; k_ < 6; ++k_) {
+                for (int k_ = 0; k_ < 12; ++k_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x020, 6, 0);
                 }
