@@ -189,6 +189,10 @@ struct OutArgs {
     int NB;
 };
 
+#ifndef VQW_WG_PAT_A
+#define VQW_WG_PAT_A 4     // weight-gradient loop: VALU / LDS instructions per MFMA while a chunk is converted ...
+#define VQW_WG_PAT_B 2      // ... and address computations / requests per MFMA in the second stage
+#endif
 #ifndef VQW_X3_PAT_MEM
 #define VQW_X3_PAT_MEM 1      // issue pattern of the conv main loop: LDS / global-memory instructions per MFMA ...
 #define VQW_X3_PAT_ALU 2      // ... and address computations per MFMA (tools/x3_bench.py: 1/2 measured best)
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
 #pragma unroll
                 for (int k_ = 0; k_ < 12; ++k_) {         // 1 MFMA, then ~1/12 of the group's VALU / LDS work in its shadow
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200, 12, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200, VQW_WG_PAT_A, 0);
                 }
             }
             if (do_sum && it + 1 < npairs) flush_pair(s_begin + it + 1);
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
 #pragma unroll
                 for (int k_ = 0; k_ < 12; ++k_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x020, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x020, VQW_WG_PAT_B, 0);
                 }
             }
             __syncthreads();
