@@ -83,8 +83,10 @@ def main():
         model.use_ema_weights()                # generate.py:88-90
     save_path = args.restore_path.split('/weights')[0]
     if rank == 0:
-        np.save(save_path + '/embedding_%d.npy' % gs, model.P['embedding'].cpu().numpy())
-        np.save(save_path + '/speaker_embedding_%d.npy' % gs, model.P['speaker_embedding'].cpu().numpy())
+        if model.use_vq:                      # generate.py:96-101
+            np.save(save_path + '/embedding_%d.npy' % gs, model.P['embedding'].cpu().numpy())
+        if model.spk_table:
+            np.save(save_path + '/speaker_embedding_%d.npy' % gs, model.P['speaker_embedding'].cpu().numpy())
 
     mine = list(range(rank, len(ids), world))  # shard speakers over GPUs: no collective needed
     if mine:

@@ -73,7 +73,8 @@ def init_params(mcfg, wcfg, num_speakers, seed=0, randomize_all=False):
             return torch.from_numpy((base + s * rng.standard_normal(n)).astype(np.float32))
         return torch.full((n,), float(base))
 
-    P['speaker_embedding'] = _uus(rng, (num_speakers, Cs), 2.0)          # model.py:23-26
+    if Cs > 0:
+        P['speaker_embedding'] = _uus(rng, (num_speakers, Cs), 2.0)      # model.py:23-26
     if mcfg.get("encoder", "64") == "Magenta":                           # encoder.py:38-63
         Fm = 128
         P['encoder/preprocess/kernel'] = _uus(rng, (5, 1, Fm), 1.0)
@@ -106,9 +107,10 @@ def init_params(mcfg, wcfg, num_speakers, seed=0, randomize_all=False):
         P[bn_scope(6) + '/beta'] = small(D)
         P[bn_scope(6) + '/moving_mean'] = torch.zeros(D)
         P[bn_scope(6) + '/moving_variance'] = torch.ones(D)
-    P['embedding/embedding'] = _uus(rng, (mcfg["k"], D), 1.7)            # model.py:47-49
+    if mcfg.get("use_vq", True):                                         # model.py:137-138: only built under use_vq
+        P['embedding/embedding'] = _uus(rng, (mcfg["k"], D), 1.7)        # model.py:47-49
 
-    Cc = D + Cs                                                          # decoder_ops.py:39-43
+    Cc = D + (Cs if Cs > 0 else num_speakers)                            # decoder_ops.py:39-43 (Cs = 0: the one-hot itself)
     Rf, Sf, Df = wcfg["residual_filters"], wcfg["skip_filters"], wcfg["dilation_filters"]
     pk, pf = wcfg["preprocess"]["kernel_size"], wcfg["preprocess"]["filters"]
     P['decoder/preprocess/kernel'] = _uus(rng, (pk, 1, pf), 1.0)          # wavenet.py:42-44
@@ -244,7 +246,11 @@ def forward(x, speaker_idx, P, mcfg, wcfg, collect=None):
         q, e_k, z_q = discretise(z_e, P['embedding/embedding'])         # model.py:57-74
     else:
         q, e_k, z_q = None, z_e, z_e
-    h = P['speaker_embedding'][speaker_idx].unsqueeze(1)                 # model.py:22-27
+    if mcfg["speaker_embedding"] > 0:
+        h = P['speaker_embedding'][speaker_idx].unsqueeze(1)             # model.py:22-27
+    else:                                                                # model.py:19-21: self.h stays the one-hot [B,1,S]
+        S = P['decoder/postprocess1/local_condition/kernel'].shape[1] - mcfg["latent_dim"]
+        h = torch.nn.functional.one_hot(speaker_idx, S).float().unsqueeze(1)
     local_condition = R.concat(z_q, h)                                   # decoder.py:30-31
     logits, labels = wavenet_build(x, local_condition, P, wcfg, collect)
     ce = torch.nn.functional.cross_entropy(logits, labels.long(), reduction='mean')

@@ -464,6 +464,37 @@ def test_encode_one_utterance_many_speakers_and_small_workspace(pkg):
     assert not any(k[2] for k in model._ws), 'encode() built a training workspace'
 
 
+@pytest.mark.parametrize('variant', ['no_vq', 'one_hot_speaker', 'both'])
+def test_config_variants_use_vq_false_and_one_hot_speakers(pkg, variant):
+    """model_parameters.json variants of the reference: use_vq=false (z_q = e_k = z_e, reconstruction loss only,
+    no codebook variable: model.py:137-141) and speaker_embedding=0 (the one-hot speaker vector itself is concatenated
+    as the global condition: model.py:19-27, decoder_ops.py:39-43; 10 speakers -> a 26-channel condition that the
+    kernels pad to 32).  Two train steps against the oracle, then generation through the padded condition."""
+    m, w = tiny_cfg()
+    if variant in ('no_vq', 'both'):
+        m = dict(m, use_vq=False)
+    if variant in ('one_hot_speaker', 'both'):
+        m = dict(m, speaker_embedding=0)
+    worst = run_parity(pkg, m, w, 10, 2, 512, seed=31, steps=2)
+    P = M.init_params(m, w, 10, seed=31, randomize_all=True)
+    assert ('embedding/embedding' in P) == m['use_vq'] and ('speaker_embedding' in P) == (m['speaker_embedding'] > 0)
+    model = build(pkg, m, w, 10, P)
+    assert set(model.named_parameters()) == set(P)
+    if m['speaker_embedding'] == 0:
+        assert model.Cc == 16 + 16 and tuple(P['decoder/postprocess1/local_condition/kernel'].shape) == (1, 26, 64)
+    x, spk, _ = M.synthetic_batch(2, 512, 10, 1234)
+    with torch.no_grad():
+        enc_ref = M.forward(x, spk, P, m, w)['local_condition']
+    enc = model.encode(x[:, :, 0].contiguous().cuda(), spk.cuda())
+    assert relerr(enc[:, :enc_ref.shape[2]].permute(0, 2, 1), enc_ref) < 1e-5 and float(enc[:, enc_ref.shape[2]:].abs().max() if enc.shape[1] > enc_ref.shape[2] else 0.0) == 0.0
+    gen = pkg.generator.FastGenerator(model, batch=2)
+    audio, idx = gen.generate(enc, 40)
+    gen.close()
+    want_idx, want_audio = M.generate(P, w, enc_ref[:, :1].expand(-1, 40, -1), 40, 'greedy')    # frame 0 for all 40 steps (ratio 64)
+    assert (idx.cpu().numpy() == want_idx).mean() > 0.9          # greedy decisions (a near-tie may part the runs)
+    print('variant', variant, 'worst grad', worst)
+
+
 def test_magenta_encoder_model_parity(pkg):
     """Encoder_Magenta (encoder.py:29-63) wired into the same VQ + decoder: two full train steps."""
     m, w = tiny_cfg()

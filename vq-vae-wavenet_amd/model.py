@@ -64,10 +64,14 @@ class VQVAE:
         self.Kc = model_cfg['k']
         self.Cs = model_cfg['speaker_embedding']
         self.beta = float(model_cfg['beta'])
-        self.use_vq = bool(model_cfg.get('use_vq', True))
-        if not self.use_vq or self.Cs <= 0:
-            raise NotImplementedError('this build implements the default use_vq=true, speaker_embedding>0 path')
-        self.Cc = self.D + self.Cs
+        self.use_vq = bool(model_cfg.get('use_vq', True))     # false: z_q = e_k = z_e, reconstruction loss only (model.py:139-141)
+        # speaker_embedding = 0: the one-hot speaker vector itself is the global condition (model.py:19-27 leaves self.h
+        # as [B, 1, num_speakers]); its width is padded to a multiple of 16 channels for the conv engine (the extra
+        # condition rows are always zero, their kernel rows never receive a gradient)
+        self.spk_table = self.Cs > 0
+        self.Cs_eff = self.Cs if self.spk_table else (num_speakers + 15) // 16 * 16
+        self.Cc_ref = self.D + (self.Cs if self.spk_table else num_speakers)      # the reference's condition width
+        self.Cc = self.D + self.Cs_eff
         self.magenta = {'Magenta': EncoderMagenta, '2019': Encoder2019}[self.enc](self.D) if self.enc != '64' else None
         w = wavenet_cfg
         self.dil = list(w['dilation_rates'])
@@ -134,7 +138,8 @@ class VQVAE:
     def _build_layout(self):
         F, D, R, S, Q, L, ks, Cc = self.F, self.D, self.R, self.S, self.Q, self.L, self.ks, self.Cc
         seg = OrderedDict()  # internal (grouped) tensors of the flat buffer
-        seg['speaker_embedding'] = (self.S_spk, self.Cs)
+        if self.spk_table:
+            seg['speaker_embedding'] = (self.S_spk, self.Cs)
         if self.enc == '64':
             seg['enc_w0'] = (5, F)                 # conv1d/kernel [5,1,F]
             seg['enc_w'] = (5, 5, F, F)            # conv1d_1..5/kernel
@@ -192,7 +197,10 @@ class VQVAE:
 
         F, D, R, S, Q, L, ks, Cc = self.F, self.D, self.R, self.S, self.Q, self.L, self.ks, self.Cc
         P = self.P
-        P['speaker_embedding'].copy_(uus((self.S_spk, self.Cs), self.S_spk, 2.0))   # model.py:23-26
+        if self.spk_table:
+            P['speaker_embedding'].copy_(uus((self.S_spk, self.Cs), self.S_spk, 2.0))   # model.py:23-26
+        else:
+            self.onehot = torch.eye(self.S_spk, self.Cs_eff, device=dev)              # row s = one_hot(s), zero padded
         if self.enc == '64':
             P['enc_w0'].copy_(glorot((5, F), 5, 1, F))
             P['enc_w'].copy_(glorot((5, 5, F, F), 5, F, F))
@@ -204,7 +212,7 @@ class VQVAE:
         P['pre_w'].copy_(uus((self.pre_k, R), self.pre_k, 1.0))                     # wavenet_ops.py:69
         P['skip0_w'].copy_(uus((R, S), R, 1.0))
         P['gated_w'].copy_(uus((L, ks, R, 2 * R), ks * R, 1.0))
-        P['cond_w'].copy_(uus((Cc, self.Mall), Cc, 1.0))
+        P['cond_w'].copy_(uus((Cc, self.Mall), self.Cc_ref, 1.0))
         P['out_w'].copy_(uus((L, R, S + R), R, 1.0))
         P['post1_w'].copy_(uus((S, S), S, 1.0))
         P['post2_w'].copy_(uus((S, Q), S, 1.0))
@@ -230,7 +238,8 @@ class VQVAE:
         """Reference TF variable name -> tensor (copy) with the reference shape."""
         F, D, R, S, L = self.F, self.D, self.R, self.S, self.L
         out = OrderedDict()
-        out['speaker_embedding'] = V['speaker_embedding']
+        if self.spk_table:
+            out['speaker_embedding'] = V['speaker_embedding']
         if self.enc == '64':
             out['encoder/conv1d/kernel'] = V['enc_w0'].reshape(5, 1, F)
             for i in range(1, 6):
@@ -249,7 +258,8 @@ class VQVAE:
                     out['encoder/batch_normalization%s/moving_variance' % _suffix(i)] = self.bn_var[sl]
         else:
             self.magenta.named(V, out)
-        out['embedding/embedding'] = V['embedding']
+        if self.use_vq:          # (the reference only creates the codebook under use_vq, model.py:137-138)
+            out['embedding/embedding'] = V['embedding']
         out['decoder/preprocess/kernel'] = V['pre_w'].reshape(self.pre_k, 1, R)
         out['decoder/preprocess/bias'] = V['pre_b']
         out['decoder/skip/kernel'] = V['skip0_w'].reshape(1, R, S)
@@ -259,14 +269,14 @@ class VQVAE:
             s = layer_scope(l, ncl)
             out[s + '/gated/kernel'] = V['gated_w'][l]
             out[s + '/gated/bias'] = V['gated_b'][l]
-            out[s + '/gated/local_condition/kernel'] = V['cond_w'][:, l * 2 * R:(l + 1) * 2 * R].unsqueeze(0)
+            out[s + '/gated/local_condition/kernel'] = V['cond_w'][:self.Cc_ref, l * 2 * R:(l + 1) * 2 * R].unsqueeze(0)
             out[s + '/skip/kernel'] = V['out_w'][l][:, :S].unsqueeze(0)
             out[s + '/skip/bias'] = V['out_b'][l][:S]
             out[s + '/residual/kernel'] = V['out_w'][l][:, S:].unsqueeze(0)
             out[s + '/residual/bias'] = V['out_b'][l][S:]
         out['decoder/postprocess1/kernel'] = V['post1_w'].reshape(1, S, S)
         out['decoder/postprocess1/bias'] = V['post1_b']
-        out['decoder/postprocess1/local_condition/kernel'] = V['cond_w'][:, L * 2 * R:].unsqueeze(0)
+        out['decoder/postprocess1/local_condition/kernel'] = V['cond_w'][:self.Cc_ref, L * 2 * R:].unsqueeze(0)
         out['decoder/postprocess2/kernel'] = V['post2_w'].reshape(1, S, self.Q)
         out['decoder/postprocess2/bias'] = V['post2_b']
         return out
@@ -429,9 +439,15 @@ class VQVAE:
     def _quantise(self, spk, ws):
         """model.py:57-74 (VQ) + model.py:22-27 / decoder_ops.py:39-43 (speaker embedding tiled over time)."""
         P, D, Tz = self.P, self.D, ws['Tz']
-        K.vq_nearest_fwd(ws['z_e'], P['embedding'], idx=ws['idx'], e_k=ws['e_k'], zq=ws['cond'],
-                         zq_bstride=self.Cc * Tz, mind=ws['mind'])
-        K.speaker_tile_fwd(P['speaker_embedding'], spk, ws['cond'], cond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs, Tz=Tz)
+        if self.use_vq:
+            K.vq_nearest_fwd(ws['z_e'], P['embedding'], idx=ws['idx'], e_k=ws['e_k'], zq=ws['cond'],
+                             zq_bstride=self.Cc * Tz, mind=ws['mind'])
+        else:                       # z_q = e_k = z_e (model.py:139-141): a copy, no quantisation losses
+            ws['cond'][:, :D].copy_(ws['z_e'])
+            ws['idx'].zero_()
+            ws['mind'].zero_()
+        K.speaker_tile_fwd(P['speaker_embedding'] if self.spk_table else self.onehot, spk, ws['cond'],
+                           cond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs_eff, Tz=Tz)
 
     def _decode_train(self, x, ws, save=True):
         """wavenet.py:24-100 -> ws['logits'] [B][Q][T], ws['labels']."""
@@ -533,7 +549,7 @@ class VQVAE:
         """(loss, reconstruction, vq, commitment) as python floats (synchronises)."""
         v = self.loss_buf.tolist()
         recon = v[0] / (ws['B'] * ws['T'])
-        vq = v[1] / (ws['B'] * ws['Tz'] * self.D)          # model.py:100
+        vq = v[1] / (ws['B'] * ws['Tz'] * self.D) if self.use_vq else 0.0   # model.py:100
         commit = self.beta * vq                             # model.py:103 (same forward value)
         return recon + vq + commit, recon, vq, commit
 
@@ -702,10 +718,14 @@ class VQVAE:
         if self.grad_sync is not None:      # decoder gradients are final: exchange them under the encoder backward
             self.grad_sync.bucket_ready(self.seg_off['pre_w'][0], self.n_flat)
         # ---- speaker embedding + VQ (model.py:22-27, 57-74, 99-106)
-        K.speaker_tile_bwd(ws['dcond'], spk, G['speaker_embedding'], dcond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs, Tz=Tz)
+        if self.spk_table:
+            K.speaker_tile_bwd(ws['dcond'], spk, G['speaker_embedding'], dcond_bstride=self.Cc * Tz, row0=D, Cs=self.Cs, Tz=Tz)
         nd = float(B * Tz * D)
-        K.vq_nearest_bwd(ws['z_e'], ws['e_k'], ws['idx'], dzq=ws['dcond'], dzq_bstride=self.Cc * Tz, dz_e=ws['dz'],
-                         demb=G['embedding'], cscale=2.0 * self.beta / nd, escale=2.0 / nd, K=self.Kc)
+        if self.use_vq:
+            K.vq_nearest_bwd(ws['z_e'], ws['e_k'], ws['idx'], dzq=ws['dcond'], dzq_bstride=self.Cc * Tz, dz_e=ws['dz'],
+                             demb=G['embedding'], cscale=2.0 * self.beta / nd, escale=2.0 / nd, K=self.Kc)
+        else:
+            ws['dz'].copy_(ws['dcond'][:, :D])
         if self.enc != '64':
             self.magenta.backward(x, ws, P, G, Tt)
             if self.grad_sync is not None:
@@ -838,8 +858,8 @@ class VQVAE:
         if Bx == B:
             return ws['cond'].clone()
         cond = ws['cond'].repeat(B, 1, 1)
-        K.speaker_tile_fwd(self.P['speaker_embedding'], spk, cond, cond_bstride=self.Cc * ws['Tz'], row0=self.D,
-                           Cs=self.Cs, Tz=ws['Tz'])
+        K.speaker_tile_fwd(self.P['speaker_embedding'] if self.spk_table else self.onehot, spk, cond,
+                           cond_bstride=self.Cc * ws['Tz'], row0=self.D, Cs=self.Cs_eff, Tz=ws['Tz'])
         return cond
 
     def free_workspaces(self):
