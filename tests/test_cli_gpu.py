@@ -32,6 +32,12 @@ def test_train_then_generate_roundtrip(tmp_path):
     assert '[step 4]' in out.stdout and 'recons' in out.stdout
     ckpt = tmp_path / 'saved_model' / 'weights-4.pt'
     assert ckpt.exists()
+    # the reference's TensorBoard tags (model.py:28-69,95-104), one JSON line per logged step
+    lines = [json.loads(ln) for ln in (tmp_path / 'saved_model' / 'summaries.jsonl').read_text().splitlines()]
+    assert [ln['global_step'] for ln in lines] == [2, 4]
+    for tag in ('z_e', 'z_e_u', 'z_e_v', 'embedding', 'embedding_u', 'speaker_embedding', 'e_k', 'q(z|x)'):
+        assert len(lines[-1][tag]['counts']) == 30 and lines[-1][tag]['min'] <= lines[-1][tag]['mean'] <= lines[-1][tag]['max'], tag
+    assert lines[-1]['reconstruction_loss'] > 0 and lines[-1]['vq_loss'] >= 0 and sum(lines[-1]['q(z|x)']['counts']) == 2 * 512 // 64
     sd = torch.load(str(ckpt), map_location='cpu', weights_only=True)
     assert int(sd['global_step']) == 4 and not torch.equal(sd['flat'], sd['ema'])
     # resume continues the step counter

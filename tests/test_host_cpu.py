@@ -185,6 +185,24 @@ def test_wav_dataset_and_speaker_map(pkg, tmp_path):
     pf.close()
 
 
+def test_visualise_exports_projector_tsv(tmp_path):
+    """visualise.py (reference visualise.py:6-49): <name>_vecs.tsv + <name>_meta.tsv for the embedding projector."""
+    (tmp_path / 'data').mkdir()
+    (tmp_path / 'data' / 'vctk_speakers.txt').write_text('p225, 0\np226, 1\np300, 2\n')
+    (tmp_path / 'data' / 'vctk_speaker_info.txt').write_text(
+        'ID  AGE  GENDER  ACCENTS  REGION\n225  23  F    English    Southern  England\n226  22  M    English    Surrey\n')
+    np.save(str(tmp_path / 'embedding_7.npy'), np.arange(6, dtype=np.float32).reshape(3, 2))
+    np.save(str(tmp_path / 'speaker_embedding_7.npy'), np.ones((3, 2), np.float32))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'visualise.py'), '-embedding', str(tmp_path / 'embedding_7.npy'),
+                          '-speaker', str(tmp_path / 'speaker_embedding_7.npy'), '-save', str(tmp_path / 'proj')],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert (tmp_path / 'proj' / 'embedding_7_vecs.tsv').read_text() == '0.0\t1.0\n2.0\t3.0\n4.0\t5.0\n'
+    assert (tmp_path / 'proj' / 'embedding_7_meta.tsv').read_text() == '1\n2\n3\n'
+    assert (tmp_path / 'proj' / 'speaker_embedding_7_meta.tsv').read_text() == \
+        '23#F#English#Southern#England\n22#M#English#Surrey\nmissing_info\n'
+
+
 def test_cli_surface_matches_reference_flags():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'train.py'), '-h'], text=True)
     for flag in ('-dataset', '-length', '-step', '-batch', '-interval', '-restore', '-save', '-params'):

@@ -99,6 +99,10 @@ def main():
             progress = '\r[step %d] %.2f' % (gs, step / args.num_steps * 100) + '%'
             msg = ' [recons %.5f] [vq %.5f] [lr %.5f]' % (rl, vq, model.lr_at(gs - 1))
             print(progress + msg + display_time(t, (args.num_steps - step) * t), end='', flush=True)
+            # the reference writes its merged summaries to a TensorBoard event file here (train.py:104-109); without
+            # TensorFlow the same tags go to <save_dir>/summaries.jsonl, one line per logged step
+            with open(os.path.join(save_dir, 'summaries.jsonl'), 'a') as f:
+                f.write(json.dumps({'global_step': gs, 'learning_rate': model.lr_at(gs - 1), **model.summaries(ws)}) + '\n')
     if rank == 0:
         torch.cuda.synchronize()
         path = '%s-%d.pt' % (args.save_path, model.global_step)

@@ -553,6 +553,42 @@ class VQVAE:
         commit = self.beta * vq                             # model.py:103 (same forward value)
         return recon + vq + commit, recon, vq, commit
 
+    def summaries(self, ws, bins=30):
+        """What the reference hands to TensorBoard every `-interval` steps (model.py:28-69,95-104; train.py:104-109), as plain
+        numbers: for every histogram tag its min / max / mean / std and `bins` equal-width counts, plus the loss scalars.
+        `_u` / `_v` are the mean / variance over the last (feature) axis, as tf.nn.moments(x, [-1]).  The reference's
+        'distances' histogram is over the [B, Tz, K] tensor this build never materialises; 'distances_min' (the distance to
+        the chosen code) stands in for it.  Synchronises."""
+        def hist(t):
+            t = t.detach().float().reshape(-1)
+            lo, hi = float(t.min()), float(t.max())
+            counts = torch.histc(t, bins=bins, min=lo, max=hi if hi > lo else lo + 1.0)
+            return {'min': lo, 'max': hi, 'mean': float(t.mean()), 'std': float(t.std()) if t.numel() > 1 else 0.0,
+                    'counts': [int(c) for c in counts.tolist()]}
+
+        def moments(t):          # features on the last axis
+            return t.mean(-1), t.var(-1, unbiased=False)
+        out = {}
+        z_e = ws['z_e'].permute(0, 2, 1)                    # [B, Tz, D] as the reference holds it
+        tags = {'z_e': z_e}
+        if self.spk_table:
+            tags['speaker_embedding'] = self.P['speaker_embedding']
+        if self.use_vq:
+            tags['embedding'] = self.P['embedding']
+            tags['e_k'] = ws['e_k'].permute(0, 2, 1)
+            out['q(z|x)'] = hist(ws['idx'])
+            out['distances_min'] = hist(ws['mind'])
+        for name, t in tags.items():
+            out[name] = hist(t)
+            if name != 'e_k':
+                u, v = moments(t)
+                out[name + '_u'], out[name + '_v'] = hist(u), hist(v)
+        loss, recon, vq, commit = self.losses(ws)
+        out['reconstruction_loss'] = recon
+        if self.use_vq:
+            out['vq_loss'], out['commitment_loss'] = vq, commit
+        return out
+
     # ------------------------------------------------------------------ backward
     def _transpose_weights(self):
         P, Tt, L, ks, R, S, F = self.P, self.T, self.L, self.ks, self.R, self.S, self.F
