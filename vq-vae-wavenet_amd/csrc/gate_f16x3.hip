@@ -317,14 +317,23 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
         // No conditionals in the body (they would cut it into scheduling regions): past the last stages the commit rewrites
         // stale registers into an LDS stage nobody reads again and the requests run past the end of the weight planes,
         // where raw buffer loads return zero.
+        // (VQW_ABL_*: timing ablations, wrong results, never shipped -- which of the three data paths bounds the loop)
+#ifndef VQW_ABL_NOLDSREAD
         read_b(bn, sn);
+#endif
+#ifndef VQW_ABL_NOCOMMIT
         rcommit(s + 2, rg);
+#endif
+#ifndef VQW_ABL_NOGLOBAL
         rissue(s + 4, rg);
+#endif
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
             mfma_rows(i, bc);
+#ifndef VQW_ABL_NOLDSREAD
             read_a(i, sn);
             read_a(i + 1, sn);
+#endif
         }
         // issue order: one MFMA, then one LDS / global-memory instruction and a few address computations in its shadow
 #pragma unroll
