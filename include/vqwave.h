@@ -312,10 +312,16 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
  * fp32 accumulators (DESIGN.md 3.2b for the error analysis and measurements).
  * Plane layout: [plane 0..1][channel chunk of 8][row][8 fp16] (16-byte entries); 2 * rows * channels bytes each.    */
 
-/* `mode` (every vqw_f16x3_* entry point / descriptor): 0 = the fp16x3 engine described above; 1 = the bf16 engine of
- * BASELINE.json configs[4] -- bf16 storage + fp32 accumulate: ONE bf16 plane per operand (planes buffers hold only the
- * first plane: rows * channels * 2 bytes), one v_mfma_f32_32x32x16_bf16 per product; same layouts, same kernels, no
- * range scales needed (bf16 has fp32's exponent range).  Operands written in one mode must be consumed in the same.   */
+/* `mode` (every vqw_f16x3_* entry point / descriptor) is a bit set:
+ *   VQW_X3_BF16        the bf16 engine of BASELINE.json configs[4] -- bf16 storage + fp32 accumulate: ONE bf16 plane per
+ *                      operand (planes buffers hold only the first plane), one v_mfma_f32_32x32x16_bf16 per product; no
+ *                      range scales needed.  Operands written in one plane format must be consumed in the same.
+ *   VQW_X3_HALF_BLOCKS conv kernels with 128-row blocks, two resident blocks per CU (one block's HBM-bound epilogue
+ *                      overlaps the other's MFMA loop).  Results are the same; vqw_f16x3_pack_gate_weights must be given
+ *                      the same bit as the gate conv that reads its planes (the filter / gate row order follows the
+ *                      block height).  No effect on the other entry points.                                          */
+#define VQW_X3_BF16 1
+#define VQW_X3_HALF_BLOCKS 2
 
 /* Range guards.  The leading plane of scale * x must stay inside fp16 (|.| <= 65504).  Scales are powers of two held in
  * DEVICE memory, chosen from measured max-abs values with no host round trip:
@@ -359,7 +365,7 @@ typedef struct vqw_f16x3_gate_desc {
                                              * chunk kc0 (several layers side by side); 0, 0 = exactly this layer's R/8 */
     const float* x_scale;  /* device scalars (or NULL = 1): the scales xp and wp were written with; the accumulators */
     const float* w_scale;  /* are multiplied by w_scale_inv / (x_scale * w_scale)                                    */
-    int32_t mode;          /* 0: fp16x3; 1: bf16 (see below)                                                         */
+    int32_t mode;          /* VQW_X3_* bits (see below)                                                              */
 } vqw_f16x3_gate_desc;
 /* T % 256 == 0, R % 128 == 0, (T / cond_T) % 32 == 0; tap j reads x[t - (ks-1-j)*dilation], zero before t = 0 */
 int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
@@ -400,7 +406,7 @@ typedef struct vqw_f16x3_out_desc {
     const float* out_scale; /* device scalar (or NULL = 1): net_out_planes hold plane_scale * out_scale * net_out   */
     uint32_t* out_amax;    /* atomicMax of the bit pattern of max |net_out| (or NULL)                                */
     int32_t* flag;         /* |= 1 when plane_scale * out_scale * |net_out| > 65504 or net_out is not finite (or NULL) */
-    int32_t mode;          /* 0: fp16x3; 1: bf16                                                                      */
+    int32_t mode;          /* VQW_X3_* bits                                                                          */
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 
@@ -434,7 +440,7 @@ typedef struct vqw_f16x3_wgrad_desc {
     int64_t seg_bstride;
     int32_t seg_T;
     int32_t total_o0, total_o1;   /* 0, 0 = all of [0, Q0 + Q1)                                              */
-    int32_t mode;           /* 0: fp16x3; 1: bf16                                                            */
+    int32_t mode;           /* VQW_X3_* bits                                                                 */
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
 

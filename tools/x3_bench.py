@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module('vq-vae-wavenet_amd')
 K = pkg.kernels
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+print('VQW_X3_HALF =', os.environ.get('VQW_X3_HALF', K.DEFAULT_X3_HALF))
 B, T, R, S, ks = 8, 6656, 256, 512, 3
 dev = 'cuda'
 g = torch.Generator().manual_seed(0)

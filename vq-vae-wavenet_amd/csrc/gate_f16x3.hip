@@ -142,7 +142,7 @@ __global__ void update_scales_kernel(unsigned* amax, float* scale, int n, int ta
 // rows in block order: row m' = 256 mt + i is filter channel 128 mt + i (i < 128) or gate channel 128 mt + i - 128
 template <bool BF>
 __global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int ks, int R, int ldw, float scale,
-                                   const float* __restrict__ scale_dev) {
+                                   const float* __restrict__ scale_dev, int hb) {     // hb: rows of a block (256 or 128)
     scale *= dev_scale(scale_dev);
     const int M = 2 * R, KC = ks * R / 8;
     w += (size_t)blockIdx.y * ks * R * ldw;          // one layer per grid row
@@ -150,8 +150,8 @@ __global__ void pack_gate_w_kernel(const float* __restrict__ w, uint4* __restric
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= KC * M) return;
     const int mp = i % M, kc = i / M;
-    const int mt = mp / 256, ii = mp % 256;
-    const int col = ii < 128 ? 128 * mt + ii : R + 128 * mt + (ii - 128);
+    const int mt = mp / hb, ii = mp % hb, hh = hb / 2;          // a block holds hh filter rows, then the hh matching gate rows
+    const int col = ii < hh ? hh * mt + ii : R + hh * mt + (ii - hh);
     const int j = kc / (R / 8), c0 = (kc % (R / 8)) * 8;
     float v[8];
 #pragma unroll
@@ -212,70 +212,94 @@ struct LoopGeom {
     int dir, T;      // dir > 0: tap j reads x[t - (ks-1-j) d] (causal conv); dir < 0: x[t + (ks-1-j) d] (its input gradient)
 };
 
-// acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: 16 accumulator tiles per wave, operands through
-// VGPRs into the 4-stage LDS ring, fragments double-buffered in registers, one barrier per step.
-template <bool BF>
-__device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, const LoopGeom& g, int wv, int lane) {
-    constexpr int NP = BF ? 1 : 2;        // planes per operand; a wave moves 2 * NP weight and 2 * NP activation pieces per step
+// acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: MR x 2 accumulator tiles per wave, operands through
+// VGPRs into an LDS ring, one barrier per K step of 16.
+//   MR = 8: block = 256 rows x 256 columns, 16 accumulator tiles (256 AGPRs) per wave, one block per CU, 4 LDS stages of
+//           32 KiB, two stages of requests in flight.
+//   MR = 4: block = 128 rows x 256 columns, 8 accumulator tiles per wave, 256 registers per wave => TWO blocks per CU
+//           (3 stages of 24 KiB each): while one block is in its HBM-bound epilogue (all blocks of a one-block-per-CU
+//           grid reach it together: gate backward spent 64 % of its time there) the other block's MFMAs run; each weight
+//           panel is read by twice as many blocks (all of the loop's data movement is 16 % of the MR = 8 kernel).
+// Two blocks that share a CU start together and would reach their epilogues together; the blocks of every second
+// batch of `CUs` block ids wait a fraction of a main loop first, so that one block stores while the other multiplies.
+#ifndef VQW_X3_STAGGER
+#define VQW_X3_STAGGER 0      // in units of 8128 cycles (~3.7 us)
+#endif
+__device__ __forceinline__ void x3_stagger(int n) {
+    if (VQW_X3_STAGGER > 0 && ((blockIdx.x >> 8) & 1))
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+template <int MR> struct X3Shape {
+    static constexpr int NSTAGE = MR == 8 ? 4 : 3;
+    static constexpr int STAGE_BYTES = (MR * 2 + 16) * 1024;     // MR*2 weight pieces + 16 activation pieces of 1 KiB
+    static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+    static constexpr int DEPTH = MR == 8 ? 2 : 1;                 // stages of requests in flight
+};
+template <bool BF, int MR>
+__device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem, const LoopGeom& g, int wv, int lane) {
+    constexpr int NP = BF ? 1 : 2;        // planes per operand
+    constexpr int NA = MR * NP / 4, NBP = 2 * NP;      // weight / activation pieces a wave moves per step
+    if (MR == 4) x3_stagger(VQW_X3_STAGGER);
+    constexpr int NSTG_ = X3Shape<MR>::NSTAGE, STGB = X3Shape<MR>::STAGE_BYTES, BOFF = MR * 2 * 1024, DEPTH = X3Shape<MR>::DEPTH;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int KCA = g.ks * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
     const int nsteps = g.ks * spt;
     const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(g.wp, (unsigned)((size_t)2 * KCA * g.M * 16));
     const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(g.xp, (unsigned)((size_t)2 * g.xKC * g.NB * 16));
-    // Stage image: 16 weight pieces (tile i, plane p at (i * 2 + p) KiB) then 16 activation pieces.  Wave wv moves
-    // pieces wv*4 .. wv*4+3 of either kind; lane = (k half, row) as the MFMA wants it.
-    int voffA[2 * NP], voffB[2 * NP], trow[2 * NP], piece[2 * NP];
+    // Stage image: MR*2 weight pieces (row tile i, plane p at (i * 2 + p) KiB), then 16 activation pieces.  lane = (k half, row)
+    // as the MFMA wants it.
+    int voffA[NA], pieceA[NA], voffB[NBP], trow[NBP], pieceB[NBP];
 #pragma unroll
-    for (int i = 0; i < 2 * NP; ++i) {
-        const int q = wv * 2 * NP + i, tile = q / NP, p = q % NP;
-        piece[i] = tile * 2 + p;
+    for (int i = 0; i < NA; ++i) {
+        const int q = wv * NA + i, tile = q / NP, p = q % NP;
+        pieceA[i] = tile * 2 + p;
         voffA[i] = ((p * KCA + lhi) * g.M + g.m_row0 + tile * 32 + l31) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+        const int q = wv * NBP + i, tile = q / NP, p = q % NP;
+        pieceB[i] = tile * 2 + p;
         voffB[i] = ((p * g.xKC + g.xkc0 + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
         trow[i] = g.t0 + tile * 32 + l31;                    // time of this lane's activation row
     }
-    // Software pipeline of one step s (one barrier): the MFMAs run on the fragments of stage s, which were read from
-    // LDS during step s - 1; meanwhile the fragments of stage s + 1 are read into the other fragment set; behind the
-    // MFMAs stage s + 2 (requested from global memory one step ago) is written to LDS and stage s + 3 is requested.
-    // Two register sets: the requests of stages s + 2 and s + 3 are both in flight while stage s is multiplied (one
-    // step of MFMAs, ~1500 cycles, is shorter than a stage's trip from L2: 32 KiB per CU at ~14 B/cycle).
-    f32x4 rgA[4 * NP], rgB[4 * NP];
-    auto rissue = [&](int s, f32x4 (&rg)[4 * NP]) {
+    f32x4 rgA[NA + NBP], rgB[NA + NBP];
+    auto rissue = [&](int s, f32x4 (&rg)[NA + NBP]) {
         const int j = s / spt, kc = (s - j * spt) * 2;
         const int shift = (g.ks - 1 - j) * g.dilation * (g.dir < 0 ? -1 : 1);   // rows before / behind the batch row read as zero
 #pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) {
-            rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * g.M * 16, 0);
+        for (int i = 0; i < NA; ++i) rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * g.M * 16, 0);
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) {
             const int tr = trow[i] - shift;
             const int vb = (tr >= 0 && tr < g.T) ? voffB[i] + (kc * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
-            rg[2 * NP + i] = vqw_buf_load4(rb, vb, 0);
+            rg[NA + i] = vqw_buf_load4(rb, vb, 0);
         }
     };
-    auto rcommit = [&](int s, const f32x4 (&rg)[4 * NP]) {
-        char* dst = smem + (s % NSTG) * STG_BYTES + lane * 16;
+    auto rcommit = [&](int s, const f32x4 (&rg)[NA + NBP]) {
+        char* dst = smem + (s % NSTG_) * STGB + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) {
-            *reinterpret_cast<f32x4*>(dst + piece[i] * 1024) = rg[i];
-            *reinterpret_cast<f32x4*>(dst + 16 * 1024 + piece[i] * 1024) = rg[2 * NP + i];
-        }
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(dst + pieceA[i] * 1024) = rg[i];
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) *reinterpret_cast<f32x4*>(dst + BOFF + pieceB[i] * 1024) = rg[NA + i];
     };
-    // Fragments: ONE set of A fragments (8 row tiles x NP planes) that is refilled row tile by row tile -- right behind the six
+    // Fragments: ONE set of A fragments (MR row tiles x NP planes) that is refilled row tile by row tile -- right behind the
     // MFMAs of a row tile its fragments of the NEXT stage are fetched from LDS, a whole step before they are used -- and two
     // sets of this wave's B fragments.
-    uint4 fa[8][NP], fb[2][NP], fbn[2][NP];
+    uint4 fa[MR][NP], fb[2][NP], fbn[2][NP];
     auto read_a = [&](int i, int s) {
-        const char* st = smem + (s % NSTG) * STG_BYTES + lane * 16;
+        const char* st = smem + (s % NSTG_) * STGB + lane * 16;
 #pragma unroll
         for (int p = 0; p < NP; ++p) fa[i][p] = *reinterpret_cast<const uint4*>(st + (i * 2 + p) * 1024);
     };
     auto read_b = [&](uint4 (&b)[2][NP], int s) {
-        const char* st = smem + (s % NSTG) * STG_BYTES + lane * 16 + 16 * 1024;
+        const char* st = smem + (s % NSTG_) * STGB + lane * 16 + BOFF;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int p = 0; p < NP; ++p) b[j][p] = *reinterpret_cast<const uint4*>(st + ((wv * 2 + j) * 2 + p) * 1024);
     };
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -301,17 +325,18 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     };
 
     rissue(0, rgA); rcommit(0, rgA);
-    rissue(1, rgB); rcommit(1, rgB);
+    rissue(1, rgA); rcommit(1, rgA);
     rissue(2, rgA);
-    if (3 < nsteps) rissue(3, rgB);
+    if (DEPTH == 2) rissue(3, rgB);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 8; ++i) read_a(i, 0);
+    for (int i = 0; i < MR; ++i) read_a(i, 0);
     read_b(fb, 0);
-    // One step s (one barrier): stage s + 1 is complete in LDS behind the barrier; the MFMAs of stage s run row tile by row
-    // tile with the LDS reads of stage s + 1 behind them; then stage s + 2 (requested two steps ago) goes to LDS and
-    // stage s + 4 is requested.  nsteps is even (Cin % 32 == 0 is checked by the callers).
-    auto step = [&](const uint4 (&bc)[2][NP], uint4 (&bn)[2][NP], int s, f32x4 (&rg)[4 * NP]) {
+    // One step s (one barrier): stage s + 1 is complete in LDS behind the barrier and the slot of stage s is free (its
+    // fragments are in registers); the MFMAs of stage s run row-tile pair by row-tile pair with the LDS reads of stage s + 1
+    // behind them; stage s + 2 (requested DEPTH steps ago) goes to LDS and stage s + 2 + DEPTH is requested.  nsteps is even
+    // (Cin % 32 == 0 is checked by the callers).
+    auto step = [&](const uint4 (&bc)[2][NP], uint4 (&bn)[2][NP], int s, f32x4 (&rg)[NA + NBP]) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int sn = s + 1 < nsteps ? s + 1 : s;          // (the last step re-reads its own stage: no branch in the body)
         // No conditionals in the body (they would cut it into scheduling regions): past the last stages the commit rewrites
@@ -325,10 +350,10 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
         rcommit(s + 2, rg);
 #endif
 #ifndef VQW_ABL_NOGLOBAL
-        rissue(s + 4, rg);
+        rissue(s + 2 + DEPTH, rg);
 #endif
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
+        for (int i = 0; i < MR; i += 2) {
             mfma_rows(i, bc);
 #ifndef VQW_ABL_NOLDSREAD
             read_a(i, sn);
@@ -337,7 +362,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
         }
         // issue order: one MFMA, then one LDS / global-memory instruction and a few address computations in its shadow
 #pragma unroll
-        for (int k_ = 0; k_ < (BF ? 16 : 48); ++k_) {
+        for (int k_ = 0; k_ < (BF ? 2 : 6) * MR; ++k_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100 | 0x200 | 0x020, BF ? 2 : VQW_X3_PAT_MEM, 0);
             __builtin_amdgcn_sched_group_barrier(0x002 | 0x004, VQW_X3_PAT_ALU, 0);
@@ -345,7 +370,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[8][2], char* smem, 
     };
     for (int s = 0; s < nsteps; s += 2) {
         step(fb, fbn, s, rgA);
-        step(fbn, fb, s + 1, rgB);
+        step(fbn, fb, s + 1, DEPTH == 2 ? rgB : rgA);
     }
 }
 
@@ -367,23 +392,24 @@ __device__ __forceinline__ void store_plane_quad(void* planes, int KC, int NB, i
     if (!BF) *reinterpret_cast<uint2*>(base + (size_t)KC * NB * 16) = make_uint2(h2[0] | ((unsigned)h2[1] << 16), h2[2] | ((unsigned)h2[3] << 16));
 }
 
-template <bool BF>
-__global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
+template <bool BF, int MR>
+__global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_f16x3_kernel(const GateArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_gate_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int R = d.R, T = d.T;
-    const int n_mt = R / 128;
+    constexpr int HB = 32 * MR, HH = HB / 2;                 // block rows: HH filter channels, then the HH matching gate channels
+    const int n_mt = R / HH;
     const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;     // 256 | T: a block never straddles two batch rows
     const int b = n0 / T, t0 = n0 - b * T;
-    f32x16 acc[8][2];
+    f32x16 acc[MR][2];
     {
         LoopGeom g;
         g.wp = d.wp; g.xp = d.xp; g.M = 2 * R; g.Cin = R; g.ks = d.ks; g.dilation = d.dilation; g.NB = a.NB;
         g.xKC = R / 8; g.xkc0 = 0; g.dir = 1; g.T = T;
-        g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
-        f16x3_mainloop<BF>(acc, smem, g, wv, lane);
+        g.m_row0 = mt * HB; g.n0 = n0; g.t0 = t0;
+        f16x3_mainloop<BF, MR>(acc, smem, g, wv, lane);
     }
 
     // ---- epilogue: + bias + upsampled condition (add_condition, wavenet_ops.py:93-101), tanh(filter) * sigmoid(gate).
@@ -397,10 +423,10 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
     const bool s0 = d.save0 != nullptr, s1 = d.save1 != nullptr;
     const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MR / 2; ++i)
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) {
-            const int c0 = 128 * mt + 32 * i + 8 * v4 + 4 * lhi;         // first of this lane's four channels
+            const int c0 = HH * mt + 32 * i + 8 * v4 + 4 * lhi;          // first of this lane's four channels
             float addf[4][2], addg[4][2];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -421,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float xf = acc[i][j][v4 * 4 + e] * winv + addf[e][j];
-                    const float xg = acc[i + 4][j][v4 * 4 + e] * winv + addg[e][j];
+                    const float xg = acc[i + MR / 2][j][v4 * 4 + e] * winv + addg[e][j];
                     const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * xf) + 1.0f);
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-xg));
                     const int o = e * T + 32 * j;
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
             if (d.out_planes) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    store_plane_quad<BF>(d.out_planes, d.out_planes_KC > 0 ? d.out_planes_KC : R / 8, a.NB, d.out_planes_kc0 + 16 * mt + 4 * i + v4,
+                    store_plane_quad<BF>(d.out_planes, d.out_planes_KC > 0 ? d.out_planes_KC : R / 8, a.NB, d.out_planes_kc0 + (HH / 8) * mt + 4 * i + v4,
                                      n0 + 64 * wv + 32 * j + l31, lhi, gq[j]);
             }
         }
@@ -441,26 +467,27 @@ __global__ __launch_bounds__(256, 1) void gate_f16x3_kernel(const GateArgs a) {
 
 // The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
 // rows 0..S-1: skip += W_s g + b_s; rows S..S+R-1: net' = net + W_r g + b_r (and net' as planes for the next gate conv).
-template <bool BF>
-__global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
+template <bool BF, int MR>
+__global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void out_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int R = d.R, S = d.S, T = d.T, M = S + R;      // S skip rows, then R residual rows (either may be 0)
     const int Cin = d.Cin > 0 ? d.Cin : R;
-    const int n_mt = M / 256;
+    constexpr int HB = 32 * MR;
+    const int n_mt = M / HB;
     const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
     const int b = n0 / T, t0 = n0 - b * T;
-    f32x16 acc[8][2];
+    f32x16 acc[MR][2];
     {
         LoopGeom g;
         g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = Cin; g.ks = d.ks > 0 ? d.ks : 1; g.dilation = d.dilation > 0 ? d.dilation : 1; g.NB = a.NB;
         g.xKC = d.xp_KC > 0 ? d.xp_KC : Cin / 8; g.xkc0 = d.xp_kc0; g.dir = d.dir < 0 ? -1 : 1; g.T = T;
-        g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
-        f16x3_mainloop<BF>(acc, smem, g, wv, lane);
+        g.m_row0 = mt * HB; g.n0 = n0; g.t0 = t0;
+        f16x3_mainloop<BF, MR>(acc, smem, g, wv, lane);
     }
-    const bool is_skip = mt * 256 < S;    // 256 | S: a block is all skip rows or all residual rows
+    const bool is_skip = mt * HB < S;     // 256 | S: a block is all skip rows or all residual rows
     const bool hb = d.bias != nullptr;
     const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);
     const int tcol = t0 + 64 * wv + l31;
@@ -469,10 +496,10 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
     float gmax = 0.0f;
     bool gbad = false;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) {
-            const int m0 = mt * 256 + 32 * i + 8 * v4 + 4 * lhi;     // first of this lane's four rows
+            const int m0 = mt * HB + 32 * i + 8 * v4 + 4 * lhi;      // first of this lane's four rows
             const size_t off = is_skip ? ((size_t)b * S + m0) * T + tcol : ((size_t)b * R + (m0 - S)) * T + tcol;
             const bool hin = is_skip || d.net_in != nullptr;
             const float* pin = is_skip ? d.skip + off : (d.net_in ? d.net_in + off : d.net_out + off);
@@ -508,23 +535,24 @@ __global__ __launch_bounds__(256, 1) void out_f16x3_kernel(const OutArgs a) {
 // Gate backward (the transpose of gated_cnn's tanh * sigmoid, wavenet_ops.py:112-113, behind the transposed 1x1 convs):
 // dg = W_out^T [dskip; dnet] over the gradient planes (dskip in chunks 0..S/8-1, dnet behind it), then
 // dpre[filter c] = dg * sg * (1 - th^2), dpre[gate c] = dg * th * sg * (1 - sg); dpre also as planes for the input gradient.
-template <bool BF>
-__global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a) {
+template <bool BF, int MR>
+__global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int R = d.R, T = d.T;
-    const int n_mt = R / 256;
+    constexpr int HB = 32 * MR;
+    const int n_mt = R / HB;
     const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
     const int b = n0 / T, t0 = n0 - b * T;
-    f32x16 acc[8][2];
+    f32x16 acc[MR][2];
     {
         LoopGeom g;
         g.wp = d.wp; g.xp = d.xp; g.M = R; g.Cin = d.Cin; g.ks = 1; g.dilation = 1; g.NB = a.NB;
-        g.m_row0 = mt * 256; g.n0 = n0; g.t0 = t0;
+        g.m_row0 = mt * HB; g.n0 = n0; g.t0 = t0;
         g.xKC = d.xp_KC > 0 ? d.xp_KC : d.Cin / 8; g.xkc0 = d.xp_kc0; g.dir = 1; g.T = T;
-        f16x3_mainloop<BF>(acc, smem, g, wv, lane);
+        f16x3_mainloop<BF, MR>(acc, smem, g, wv, lane);
     }
     const int tcol = t0 + 64 * wv + l31;
     const float ps = (d.plane_scale > 0.0f ? d.plane_scale : 1.0f) * dev_scale(d.out_scale);
@@ -533,10 +561,10 @@ __global__ __launch_bounds__(256, 1) void gate_bwd_f16x3_kernel(const OutArgs a)
     bool gbad = false;
     const int PKC = d.planes_KC > 0 ? d.planes_KC : 2 * R / 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) {
-            const int c0 = mt * 256 + 32 * i + 8 * v4 + 4 * lhi;     // first of this lane's four gated channels
+            const int c0 = mt * HB + 32 * i + 8 * v4 + 4 * lhi;      // first of this lane's four gated channels
             const size_t offa = ((size_t)b * R + c0) * T + tcol;      // saved tanh / sigmoid [B][R][T]
             const size_t offo = ((size_t)b * 2 * R + c0) * T + tcol;  // dpre [B][2R][T]: filter rows, then gate rows
             const float* pt = d.aux0 + offa;
@@ -882,8 +910,8 @@ int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int 
     if (KC <= 0) { KC = C / 8; kc0 = 0; }
     VQW_CHECK(kc0 >= 0 && kc0 + C / 8 <= KC, "vqw_f16x3_split_activations: bad chunk range (kc0=%d KC=%d)", kc0, KC);
     const size_t n = (size_t)B * T * (C / 8);
-    VQW_CHECK(mode == 0 || mode == 1, "vqw_f16x3_split_activations: mode must be 0 (two fp16 planes) or 1 (one bf16 plane)");
-    if (mode) hipLaunchKernelGGL(split_act_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
+    VQW_CHECK(mode >= 0 && mode <= 3, "vqw_f16x3_split_activations: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS");
+    if (mode & 1) hipLaunchKernelGGL(split_act_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
                                  scale_dev, amax, flag);
     else hipLaunchKernelGGL(split_act_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
                             scale_dev, amax, flag);
@@ -896,8 +924,9 @@ int vqw_f16x3_pack_gate_weights(const float* w, void* planes, int ks, int R, int
     VQW_CHECK(w && planes, "vqw_f16x3_pack_gate_weights: null pointer");
     VQW_CHECK(ks >= 1 && R > 0 && R % 128 == 0 && ldw >= 2 * R && count >= 1 && count <= 65535, "vqw_f16x3_pack_gate_weights: needs R %% 128 == 0, ldw >= 2R, 1 <= count <= 65535 (R=%d ldw=%d count=%d)", R, ldw, count);
     const int n = (ks * R / 8) * 2 * R;
-    if (mode) hipLaunchKernelGGL(pack_gate_w_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev);
-    else hipLaunchKernelGGL(pack_gate_w_kernel<false>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev);
+    const int hb = (mode & VQW_X3_HALF_BLOCKS) ? 128 : 256;      // must match the block height of the gate conv that reads the planes
+    if (mode & 1) hipLaunchKernelGGL(pack_gate_w_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev, hb);
+    else hipLaunchKernelGGL(pack_gate_w_kernel<false>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, ks, R, ldw, scale, scale_dev, hb);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_gate_weights");
     return 0;
 }
@@ -907,7 +936,7 @@ int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, 
     VQW_CHECK(w && planes, "vqw_f16x3_pack_weights: null pointer");
     VQW_CHECK(K > 0 && K % 8 == 0 && M > 0 && ldw >= M && count >= 1 && count <= 65535, "vqw_f16x3_pack_weights: needs K %% 8 == 0, ldw >= M, 1 <= count <= 65535 (K=%d M=%d ldw=%d count=%d)", K, M, ldw, count);
     const int n = (K / 8) * M;
-    if (mode) hipLaunchKernelGGL(pack_w_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
+    if (mode & 1) hipLaunchKernelGGL(pack_w_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
     else hipLaunchKernelGGL(pack_w_kernel<false>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_weights");
     return 0;
@@ -929,24 +958,19 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     OutArgs a;
     a.d = d;
     a.NB = d.B * d.T;
-    VQW_CHECK(d.mode == 0 || d.mode == 1, "vqw_f16x3_out_conv: mode must be 0 (fp16x3) or 1 (bf16)");
-    const bool bf = d.mode == 1;
-    const void* kout = bf ? reinterpret_cast<const void*>(out_f16x3_kernel<true>) : reinterpret_cast<const void*>(out_f16x3_kernel<false>);
-    const void* kbwd = bf ? reinterpret_cast<const void*>(gate_bwd_f16x3_kernel<true>) : reinterpret_cast<const void*>(gate_bwd_f16x3_kernel<false>);
-    if (hipFuncSetAttribute(kout, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
-        return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-    if (d.epi == 1) {   // gate backward
-        VQW_CHECK(d.S == 0 && d.R > 0 && d.aux0 && d.aux1 && d.Cin > 0, "vqw_f16x3_out_conv: gate backward needs S = 0, saved tanh (aux0) and sigmoid (aux1), Cin");
-        if (hipFuncSetAttribute(kbwd, hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
-            return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-        if (bf) hipLaunchKernelGGL(gate_bwd_f16x3_kernel<true>, dim3((d.R / 256) * (a.NB / 256)), dim3(256), NSTG * STG_BYTES, st, a);
-        else hipLaunchKernelGGL(gate_bwd_f16x3_kernel<false>, dim3((d.R / 256) * (a.NB / 256)), dim3(256), NSTG * STG_BYTES, st, a);
-        VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");
-        return 0;
-    }
-    const int blocks = ((d.S + d.R) / 256) * (a.NB / 256);
-    if (bf) hipLaunchKernelGGL(out_f16x3_kernel<true>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
-    else hipLaunchKernelGGL(out_f16x3_kernel<false>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    VQW_CHECK(d.mode >= 0 && d.mode <= 3, "vqw_f16x3_out_conv: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS");
+    const bool bf = (d.mode & 1) != 0, half = (d.mode & VQW_X3_HALF_BLOCKS) != 0;
+    typedef void (*kfn_t)(OutArgs);
+    const kfn_t kouts[4] = {out_f16x3_kernel<false, 8>, out_f16x3_kernel<true, 8>, out_f16x3_kernel<false, 4>, out_f16x3_kernel<true, 4>};
+    const kfn_t kbwds[4] = {gate_bwd_f16x3_kernel<false, 8>, gate_bwd_f16x3_kernel<true, 8>, gate_bwd_f16x3_kernel<false, 4>, gate_bwd_f16x3_kernel<true, 4>};
+    const int lds = half ? X3Shape<4>::LDS_BYTES : X3Shape<8>::LDS_BYTES, hb = half ? 128 : 256;
+    const bool bwd = d.epi == 1;
+    if (bwd) VQW_CHECK(d.S == 0 && d.R > 0 && d.aux0 && d.aux1 && d.Cin > 0, "vqw_f16x3_out_conv: gate backward needs S = 0, saved tanh (aux0) and sigmoid (aux1), Cin");
+    const kfn_t kfn = (bwd ? kbwds : kouts)[(bf ? 1 : 0) + (half ? 2 : 0)];
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", lds);
+    const int rows = bwd ? d.R : d.S + d.R;
+    hipLaunchKernelGGL(kfn, dim3((rows / hb) * (a.NB / 256)), dim3(256), lds, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");
     return 0;
 }
@@ -973,18 +997,19 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
                   "vqw_f16x3_gate_conv: T / cond_T must be a multiple of 32 (T=%d cond_T=%d)", d.T, d.cond_T);
         a.ratio = d.T / d.cond_T;
     }
-    VQW_CHECK(d.mode == 0 || d.mode == 1, "vqw_f16x3_gate_conv: mode must be 0 (fp16x3) or 1 (bf16)");
-    const bool bf = d.mode == 1;
-    if (hipFuncSetAttribute(bf ? reinterpret_cast<const void*>(gate_f16x3_kernel<true>) : reinterpret_cast<const void*>(gate_f16x3_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
-        return vqw_set_error("vqw_f16x3_gate_conv: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-    const int blocks = (d.R / 128) * (a.NB / 256);
-    if (bf) hipLaunchKernelGGL(gate_f16x3_kernel<true>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
-    else hipLaunchKernelGGL(gate_f16x3_kernel<false>, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
+    VQW_CHECK(d.mode >= 0 && d.mode <= 3, "vqw_f16x3_gate_conv: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS");
+    const bool bf = (d.mode & 1) != 0, half = (d.mode & VQW_X3_HALF_BLOCKS) != 0;
+    typedef void (*kfn_t)(GateArgs);
+    const kfn_t ks4[4] = {gate_f16x3_kernel<false, 8>, gate_f16x3_kernel<true, 8>, gate_f16x3_kernel<false, 4>, gate_f16x3_kernel<true, 4>};
+    const kfn_t kfn = ks4[(bf ? 1 : 0) + (half ? 2 : 0)];
+    const int lds = half ? X3Shape<4>::LDS_BYTES : X3Shape<8>::LDS_BYTES;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return vqw_set_error("vqw_f16x3_gate_conv: cannot reserve %d bytes of LDS", lds);
+    const int blocks = (d.R / (half ? 64 : 128)) * (a.NB / 256);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_gate_conv");
     return 0;
 }
-
 
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
@@ -1024,11 +1049,11 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     VQW_CHECK((size_t)tiles * nsplit * 65536 <= (size_t)d.slab_floats, "vqw_f16x3_wgrad: slab too small (%d tiles x %d splits x 65536 floats)", tiles, nsplit);
     bool odd = false;
     for (int j = 0; j < d.ntaps; ++j) odd |= (d.tap_shift[j] & 3) != 0;
-    VQW_CHECK(d.mode == 0 || d.mode == 1, "vqw_f16x3_wgrad: mode must be 0 (fp16x3) or 1 (bf16)");
+    VQW_CHECK(d.mode >= 0 && d.mode <= 3, "vqw_f16x3_wgrad: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS (the latter has no effect here)");
     typedef void (*kfn_t)(WgArgs);
     const kfn_t ktab[4] = {wgrad_f16x3_kernel<false, false>, wgrad_f16x3_kernel<true, false>, wgrad_f16x3_kernel<false, true>,
                            wgrad_f16x3_kernel<true, true>};
-    const kfn_t kfn = ktab[(odd ? 1 : 0) + 2 * d.mode];
+    const kfn_t kfn = ktab[(odd ? 1 : 0) + 2 * (d.mode & 1)];
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
     hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);

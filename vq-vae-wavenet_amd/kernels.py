@@ -201,6 +201,21 @@ def _need_planes(t, n_halves, what):
     L.require_cuda(t)
 
 
+X3_BF16, X3_HALF_BLOCKS = 1, 2      # VQW_X3_* mode bits of include/vqwave.h
+
+
+def x3_mode(mode=None, bf16=False):
+    """mode bits of the vqw_f16x3_* calls; None: fp16x3 (or bf16) with the block height chosen by VQW_X3_HALF (default: see
+    model.py / DESIGN 3.3)."""
+    if mode is not None:
+        return mode
+    import os
+    return (X3_BF16 if bf16 else 0) | (X3_HALF_BLOCKS if os.environ.get('VQW_X3_HALF', DEFAULT_X3_HALF) == '1' else 0)
+
+
+DEFAULT_X3_HALF = '0'
+
+
 def _slot(t, what, dtype=torch.float32):
     """Device scalar (a 1-element view of the guard state) or None."""
     if t is None:
@@ -229,7 +244,8 @@ def f16x3_update_scales(amax, scale, *, target_exp, reset=True, flag=None):
     L.check(L.lib().vqw_f16x3_update_scales(L.ptr(amax), L.ptr(scale), n, target_exp, int(reset), _slot(flag, 'flag', torch.int32), L.stream()))
 
 
-def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_dev=None, amax=None, flag=None, mode=0):
+def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_dev=None, amax=None, flag=None, mode=None):
+    mode = x3_mode(mode)
     """scale * scale_dev * x [B][C][T] fp32 -> planes [2][KC or C/8][B*T][8] fp16, chunks kc0..."""
     _need(x, B * Cc * T, 'x')
     _need_planes(planes, 2 * B * T * (KC * 8 if KC else Cc), 'planes')
@@ -237,14 +253,16 @@ def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_d
                                                 _slot(amax, 'amax', torch.int32), _slot(flag, 'flag', torch.int32), mode, L.stream()))
 
 
-def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1, scale_dev=None, mode=0):
+def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1, scale_dev=None, mode=None):
+    mode = x3_mode(mode)
     """`count` layers back to back in `w` ([count][ks][R][ldw]) and in `planes`."""
     _need(w, (count - 1) * ks * R * ldw + (ks * R - 1) * ldw + 2 * R, 'w')
     _need_planes(planes, count * 2 * ks * R * 2 * R, 'planes')
     L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), mode, L.stream()))
 
 
-def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mode=0):
+def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mode=None):
+    mode = x3_mode(mode)
     """w [count][K][ldw] fp32 -> planes [count][2][K/8][M][8] fp16 of scale * scale_dev * w."""
     _need(w, (count - 1) * Kd * ldw + (Kd - 1) * ldw + M, 'w')
     _need_planes(planes, count * 2 * Kd * M, 'planes')
@@ -254,7 +272,8 @@ def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mo
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
                    net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
                    planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None, x_scale=None, w_scale=None,
-                   out_scale=None, out_amax=None, flag=None, mode=0):
+                   out_scale=None, out_amax=None, flag=None, mode=None):
+    mode = x3_mode(mode)
     cin = Cin if Cin > 0 else R
     kc_all = xp_KC if xp_KC > 0 else cin // 8
     _need_planes(xp, 2 * kc_all * 8 * B * T, 'xp')
@@ -294,7 +313,8 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
 
 def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,
                     cond_bstride=0, save0=None, save1=None, out_planes=None, out_planes_kc0=0, out_planes_KC=0, x_scale=None,
-                    w_scale=None, mode=0):
+                    w_scale=None, mode=None):
+    mode = x3_mode(mode)
     _need_planes(xp, 2 * B * R * T, 'xp')
     _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
     _need(out0, B * R * T, 'out0')
@@ -327,7 +347,8 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
 
 
 def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
-                q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=0):
+                q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=None):
+    mode = x3_mode(mode)
     """vqw_f16x3_wgrad: dw[j][c][o] += sum_{b,t} p[b][c][t+taps[j]] * q[b][o][t] on the fp16x3 engine (slab = scratch)."""
     lddw = (Q0 + Q1) if lddw is None else lddw
     dw_tap_stride = Cp * lddw if dw_tap_stride is None else dw_tap_stride

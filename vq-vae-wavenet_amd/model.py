@@ -101,7 +101,12 @@ class VQVAE:
         # VQW_DTYPE=bf16 (BASELINE.json configs[4]: bf16 storage + fp32 accumulate): the same kernels with ONE bf16 plane per
         # operand and one bf16 MFMA per product; master weights, optimiser state and the residual stream stay fp32
         self.bf16 = os.environ.get('VQW_DTYPE', model_cfg.get('dtype', 'f32')) == 'bf16'
-        self.x3_mode = 1 if self.bf16 else 0
+        # mode bits of the plane engine: bf16, and the block height of its conv kernels per call site -- 128-row blocks (two
+        # per CU) for the forward gate / residual / skip convs (decoder forward loop 6.05 vs 7.13 ms, tools/x3_chain.py),
+        # 256-row blocks for gate backward and the input gradient (7.8 vs 8.0 ms): VQW_X3_HALF / VQW_X3_HALF_BWD
+        self.x3_mode = K.X3_BF16 if self.bf16 else 0
+        self.x3_mode_fwd = self.x3_mode | (K.X3_HALF_BLOCKS if os.environ.get('VQW_X3_HALF', '1') == '1' else 0)
+        self.x3_mode_bwd = self.x3_mode | (K.X3_HALF_BLOCKS if os.environ.get('VQW_X3_HALF_BWD', '0') == '1' else 0)
         self.x3_guard = engine == 'f16x3' and ladder == '0' and not self.bf16
         self.x3_all = self.x3_guard or self.bf16          # the plane engine carries every decoder contraction, or none
         if self.x3_all:
@@ -470,7 +475,7 @@ class VQVAE:
         if self.x3_all and not (f16x3_skip and self._x3_active):   # guarded / bf16 engine: all of it or none of it
             f16x3 = f16x3_skip = f16x3_out = False
         ws['x3_used'] = bool(f16x3_skip and self.x3_all)
-        md = self.x3_mode
+        md = self.x3_mode_fwd
         gd = self.x3_guard and f16x3_skip
         sc = (lambda name, i=0: self.x3_scale[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
         am = (lambda name, i=0: self.x3_amax[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
@@ -648,7 +653,7 @@ class VQVAE:
         gbwd_x3 = dgrad_x3 and self.gbwd_f16x3 and S % 256 == 0
         full = bool(ws.get('x3_used'))
         gd = full and self.x3_guard
-        md = self.x3_mode
+        md = self.x3_mode_bwd
         if self.x3_all and not full:
             dgrad_x3 = gbwd_x3 = False
         calib = self.x3_guard and not self._x3_active     # fp32 repeat of a step: measure what the planes would have held
