@@ -181,12 +181,13 @@ def test_guarded_f16x3_engine_three_steps(pkg, monkeypatch, half):
     guards, against the oracle at the fp32 engine's tolerances for three consecutive steps: step 1 runs with the
     start-up scales, steps 2 and 3 with scales derived on the device from the max-abs values of the step before."""
     monkeypatch.setenv('VQW_X3_HALF', half)       # both block heights of the conv kernels (DESIGN 3.3), forward and backward
-    monkeypatch.setenv('VQW_X3_HALF_BWD', half)
+    for site in ('_SKIP', '_BWD', '_DGRAD'):
+        monkeypatch.setenv('VQW_X3_HALF' + site, half)
     m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
     P = M.init_params(m, w, 109, seed=3, randomize_all=True)
     x, spk, _ = M.synthetic_batch(1, 1024, 109, 1234)
     model = _guarded_model(pkg, monkeypatch, P, m, w)
-    assert model.x3_mode_fwd == model.x3_mode_bwd == (2 if half == '1' else 0)
+    assert model.x3_mode_fwd == model.x3_mode_skip == model.x3_mode_bwd == model.x3_mode_dgrad == (2 if half == '1' else 0)
     xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
     st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
     for step in range(3):

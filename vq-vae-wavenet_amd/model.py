@@ -102,11 +102,15 @@ class VQVAE:
         # operand and one bf16 MFMA per product; master weights, optimiser state and the residual stream stay fp32
         self.bf16 = os.environ.get('VQW_DTYPE', model_cfg.get('dtype', 'f32')) == 'bf16'
         # mode bits of the plane engine: bf16, and the block height of its conv kernels per call site -- 128-row blocks (two
-        # per CU) for the forward gate / residual / skip convs (decoder forward loop 6.05 vs 7.13 ms, tools/x3_chain.py),
-        # 256-row blocks for gate backward and the input gradient (7.8 vs 8.0 ms): VQW_X3_HALF / VQW_X3_HALF_BWD
+        # per CU) for the forward gate conv + residual 1x1 (decoder forward loop 6.05 vs 7.13 ms, tools/x3_chain.py) and for
+        # gate backward, 256-row blocks for the K = 7680 skip contraction and the input gradient (whole step, same box:
+        # 34.1 ms against 35.0 with 256-row blocks everywhere): VQW_X3_HALF, _SKIP, _BWD, _DGRAD
         self.x3_mode = K.X3_BF16 if self.bf16 else 0
-        self.x3_mode_fwd = self.x3_mode | (K.X3_HALF_BLOCKS if os.environ.get('VQW_X3_HALF', '1') == '1' else 0)
-        self.x3_mode_bwd = self.x3_mode | (K.X3_HALF_BLOCKS if os.environ.get('VQW_X3_HALF_BWD', '0') == '1' else 0)
+        half = lambda name, dflt: self.x3_mode | (K.X3_HALF_BLOCKS if os.environ.get(name, dflt) == '1' else 0)  # noqa: E731
+        self.x3_mode_fwd = half('VQW_X3_HALF', '1')                                        # gate conv + residual 1x1
+        self.x3_mode_skip = half('VQW_X3_HALF_SKIP', '0')                                  # the all-layers skip contraction
+        self.x3_mode_bwd = half('VQW_X3_HALF_BWD', '1')                                    # gate backward
+        self.x3_mode_dgrad = half('VQW_X3_HALF_DGRAD', '0')                                # input gradient
         self.x3_guard = engine == 'f16x3' and ladder == '0' and not self.bf16
         self.x3_all = self.x3_guard or self.bf16          # the plane engine carries every decoder contraction, or none
         if self.x3_all:
@@ -528,7 +532,7 @@ class VQVAE:
                         epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])                                       # :132-136, wavenet.py:72-73
         if f16x3_skip:   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
             K.f16x3_out_conv(xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
-                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / WS, w_scale=sc('WO'), mode=md)
+                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / WS, w_scale=sc('WO'), mode=self.x3_mode_skip)
         K.conv_gemm(x0=ws['skip'], in_relu=True, w=P['post1_w'], bias=P['post1_b'], out0=ws['h1'],
                     cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T, M=S,
                     C0=S, taps=[0])                                                       # wavenet.py:80-88
@@ -708,7 +712,7 @@ class VQVAE:
                                  w_scale_inv=1.0 / (WS * GS),
                                  net_out_planes=ws['gr'] if gbwd_x3 else None, planes_kc0=S // 8 if gbwd_x3 else 0,
                                  planes_KC=(S + R) // 8 if gbwd_x3 else 0, plane_scale=GS if gbwd_x3 else 0.0,
-                                 x_scale=sc('DP', l), w_scale=sc('WG'), out_scale=sc('G'), out_amax=am('G'), flag=flag, mode=md)
+                                 x_scale=sc('DP', l), w_scale=sc('WG'), out_scale=sc('G'), out_amax=am('G'), flag=flag, mode=self.x3_mode_dgrad)
             elif top:
                 K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
                             tile=self.tiles['dgrad'])
