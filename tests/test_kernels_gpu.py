@@ -280,6 +280,28 @@ def test_named_wrappers_pointwise(K, pkg):
     assert b'null' in L.lib().vqw_last_error().lower() or L.lib().vqw_last_error()
 
 
+def test_conv1d_v2_is_differentiable(pkg):
+    """ops.conv1d_v2 / ops.linear under torch.autograd: the gradients TF would derive (Conv2DBackpropInput,
+    Conv2DBackpropFilter, BiasAddGrad) come from vqw_causal_conv1d_{dgrad,wgrad} and match autograd through the oracle."""
+    O = pkg.ops
+    B, T, Cin, Cout, k, dil = 2, 320, 32, 48, 3, 4
+    x, w, b = rnd(B, T, Cin, seed=21), rnd(k, Cin, Cout, seed=22, s=0.1), rnd(Cout, seed=23)
+    dy = rnd(B, T, Cout, seed=24)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    R.conv1d_v2(xr, wr, br, dilations=dil).backward(dy)
+    xg, wg, bg = (g(t).requires_grad_(True) for t in (x, w, b))
+    y = O.conv1d_v2(xg, wg, bg, dilations=dil)
+    assert y.requires_grad
+    y.backward(g(dy))
+    close(y, R.conv1d_v2(x, w, b, dilations=dil), what='fwd')
+    close(xg.grad, xr.grad, what='d input')
+    close(wg.grad, wr.grad, rtol=5e-4, atol=5e-4, what='d kernel')
+    close(bg.grad, br.grad, rtol=5e-4, atol=5e-4, what='d bias')
+    v = g(rnd(B, Cin, seed=25)).requires_grad_(True)
+    O.linear(v, wg[1:2].detach(), None).sum().backward()                 # wavenet_ops.py:147-160 on [B, Cin]
+    close(v.grad, w[1].sum(-1)[None].expand(B, -1), what='linear d input')
+
+
 def test_bad_arguments_return_errors_not_faults(K, pkg):
     L = pkg._lib
     x = torch.zeros(1, 24, 64, device=DEV)

@@ -53,14 +53,57 @@ def shift_right(x):
     return torch.nn.functional.pad(x, (0, 0, 1, 0))[:, :-1, :].contiguous()
 
 
+class _CausalConv1d(torch.autograd.Function):
+    """conv1d_v2 with its TF gradients (Conv2DBackpropInput / Conv2DBackpropFilter / BiasAddGrad) through the C ABI:
+    vqw_causal_conv1d_{fwd,dgrad,wgrad}.  Stride 1, Cin a multiple of 16 (the shapes the reference differentiates)."""
+
+    @staticmethod
+    def forward(ctx, net, kernel, bias, dilations):
+        B, T, Cin = net.shape
+        k, _, Cout = kernel.shape
+        x = _bct(net)
+        y = torch.empty(B, Cout, T, device=net.device)
+        L.check(L.lib().vqw_causal_conv1d_fwd(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), B, Cin, Cout,
+                                              T, k, dilations, 1, L.stream()))
+        ctx.save_for_backward(x, kernel)
+        ctx.dil, ctx.has_bias = dilations, bias is not None
+        return _btc(y)
+
+    @staticmethod
+    def backward(ctx, dy_btc):
+        x, kernel = ctx.saved_tensors
+        B, Cin, T = x.shape
+        k, _, Cout = kernel.shape
+        dy = _bct(dy_btc)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wT = torch.empty(k, Cout, Cin, device=x.device)
+            K.transpose(kernel.contiguous(), wT, k, Cin, Cout)
+            dxc = torch.empty(B, Cin, T, device=x.device)
+            L.check(L.lib().vqw_causal_conv1d_dgrad(L.ptr(dy), L.ptr(wT), L.ptr(dxc), B, Cin, Cout, T, k, ctx.dil, L.stream()))
+            dx = _btc(dxc)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(k, Cin, Cout, device=x.device)
+            L.check(L.lib().vqw_causal_conv1d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), B, Cin, Cout, T, k, ctx.dil, L.stream()))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(Cout, device=x.device)
+            K.rowsum(dy, total=db)
+        return dx, dw, db, None
+
+
 def conv1d_v2(net, kernel, bias=None, padding='CAUSAL', dilations=1, stride=1):
     """wavenet_ops.py:59-90: always left-pads d*(k-1); the `padding` argument of the reference
     only selects VALID/SAME for the conv that follows the pad and every caller passes
-    CAUSAL/VALID."""
+    CAUSAL/VALID.  Differentiable (torch.autograd) for stride 1 and Cin % 16 == 0."""
     if padding.upper() not in ('CAUSAL', 'VALID'):
         raise NotImplementedError("padding %s not used by the reference's callers" % padding)
     B, T, Cin = net.shape
     k, _, Cout = kernel.shape
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (net, kernel, bias))
+    if needs_grad:
+        if stride != 1 or Cin % 16 != 0 or Cout % 16 != 0:
+            raise NotImplementedError('conv1d_v2 is differentiable for stride 1 and channel counts that are multiples of 16')
+        return _CausalConv1d.apply(net, kernel, bias, dilations)
     if Cin == 1:
         if dilations != 1:
             raise NotImplementedError('Cin == 1 convs are only used with dilation 1 by the reference')
