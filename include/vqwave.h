@@ -306,10 +306,10 @@ int vqw_ar_decode_run_group_async(vqw_ar_decoder* const* hs, int n, const float*
 int vqw_ar_decode_workgroups(const vqw_ar_decoder* h);
 int vqw_ar_decode_destroy(vqw_ar_decoder* h);
 
-/* ---- EXPERIMENTAL (opt-in; the fp32-MFMA engine above stays the default path): the decoder's gate conv
- * (wavenet_ops.py:104-114, conv1d_v2 k taps + add_condition + tanh*sigmoid) as an fp32-accurate contraction on the
- * fp16 matrix pipe: every operand is split into two fp16 planes (x = h1 + h2), products h1 h1 + h1 h2 + h2 h1 in
- * fp32 accumulators (DESIGN.md 3.2b for the error analysis and measurements).
+/* ---- The fp16x3 engine (the default path of model.py for the decoder's residual stack): contractions
+ * that are fp32-accurate on the fp16 matrix pipe.  Every operand is split into two fp16 planes (x = h1 + h2), products
+ * h1 h1 + h1 h2 + h2 h1 in fp32 accumulators.  The gate conv (wavenet_ops.py:104-114, conv1d_v2 k taps + add_condition
+ * + tanh*sigmoid), the 1x1 skip / residual convs, gate backward, the input gradient and the weight gradients.
  * Plane layout: [plane 0..1][channel chunk of 8][row][8 fp16] (16-byte entries); 2 * rows * channels bytes each.    */
 
 /* `mode` (every vqw_f16x3_* entry point / descriptor) is a bit set:

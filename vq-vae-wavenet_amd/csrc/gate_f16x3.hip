@@ -1,11 +1,12 @@
-// EXPERIMENTAL (opt-in, VQW_GATE_F16X3=1..5 in model.py): the decoder layers' contractions -- the gate conv
-// (wavenet_ops.py:104-114), the 1x1 skip + residual conv (:132-136; the skip path of all layers also as one
-// contraction), gate backward and the gate conv's input gradient -- as fp32-accurate contractions on the fp16 matrix
-// pipe of gfx950.  DESIGN.md 3.2b has the arithmetic and its
-// measured error: every fp32 operand is split exactly enough into two fp16 pieces, x = h1 + h2,
+// The fp16x3 engine: every contraction of the decoder's residual stack -- the gate conv
+// (wavenet_ops.py:104-114), the 1x1 residual conv (:135-136), the skip path of all layers as ONE contraction (:132-133,
+// wavenet.py:72), gate backward, the gate conv's input gradient and both weight gradients -- as fp32-accurate
+// contractions on the fp16 matrix pipe of gfx950: every fp32 operand is split into two fp16 pieces, x = h1 + h2,
 // h2 = fp16(x - h1), and  a*b ~ a1 b1 + a1 b2 + a2 b1  (every term exact in the fp32 accumulator of
-// v_mfma_f32_32x32x16_f16; the dropped a2 b2 is 2^-22 per product).  Same bytes per operand element as fp32,
-// three MFMAs of the 16x faster pipe instead of eight fp32 ones per 32x32x16 block.
+// v_mfma_f32_32x32x16_f16; the dropped a2 b2 is 2^-22 per product).  Same bytes per operand element as fp32, three
+// MFMAs of the fast pipe instead of eight fp32 ones per 32x32x16 block.  Device-side range guards (power-of-two scales
+// from measured max-abs values, a range flag) keep the leading planes inside fp16; the same kernels instantiated with
+// one bf16 plane and one bf16 MFMA per product are the bf16 engine of BASELINE.json configs[4].
 //
 // Operand planes ("chunk-major"): P[plane 0..1][channel chunk of 8][row][8 fp16]; a row is an output channel
 // (weights) or a (batch, time) position (activations).  The 16-byte entries of 32 consecutive rows are contiguous:
@@ -13,10 +14,10 @@
 // dilation shift of a tap is a row offset (rows before the start of a batch row read as zero through the buffer
 // range check: the causal left padding of conv1d_v2, wavenet_ops.py:81).
 //
-// Block = 256 output channels (gate conv: 128 filter + the 128 matching gate channels, so tanh * sigmoid meets in one
-// lane) x 256 time steps; four waves, each all 256 channels x 64 time steps (16 accumulator tiles in AGPRs); K step = 16
-// input channels of one tap; operands through VGPRs into a 4-stage LDS ring, MFMA fragments double-buffered in
-// registers (read from LDS one step ahead), one barrier per step.
+// Conv kernels: block = 256 (or 128) output rows x 256 time steps, four waves of all rows x 64 time steps (16 or 8
+// accumulator tiles); K step = 16 input channels of one tap; operands through VGPRs into an LDS ring, one barrier per
+// step, the MFMAs issued with the step's memory instructions interleaved behind them (f16x3_mainloop).  Weight-gradient
+// kernel: the fp32 operands themselves, split in registers (wgrad_f16x3_kernel).
 #include <string.h>
 
 #include "vqw_common.h"
