@@ -388,7 +388,7 @@ def test_gate_conv_full_size_properties(K, d):
 @pytest.mark.parametrize('B,T,Rr,ks,d', [(2, 512, 128, 3, 1), (2, 512, 128, 2, 7), (1, 1024, 256, 3, 64),
                                          (2, 768, 128, 3, 300), (8, 6656, 256, 3, 4), (8, 6656, 256, 3, 512)])
 def test_gate_conv_f16x3_matches_fp32_engine(K, x3half, B, T, Rr, ks, d):
-    """Experimental gate conv on the fp16 matrix pipe (two fp16 planes per operand, three MFMA terms)
+    """Gate conv of the fp16x3 engine (two fp16 planes per operand, three MFMA terms)
     against (1) the fp32-MFMA engine on the same inputs -- two fp32-accurate evaluations of wavenet_ops.py:104-114,
     equal to 2e-5 over all 13.6 M outputs of the benchmark shape -- and (2) an fp64 evaluation at sampled points, where it must be at least as close as the
     tolerance the fp32 engine is held to (2e-5).  Covers the causal zero padding (dilation beyond the tile and
@@ -444,7 +444,7 @@ def test_gate_conv_f16x3_matches_fp32_engine(K, x3half, B, T, Rr, ks, d):
 
 @pytest.mark.parametrize('B,T', [(2, 512), (8, 6656)])
 def test_out_conv_f16x3_matches_fp32_engine(K, x3half, B, T):
-    """Experimental 1x1 skip + residual conv on the fp16 matrix pipe, fed by the gate kernel's plane output and
+    """1x1 skip + residual conv of the fp16x3 engine, fed by the gate kernel's plane output and
     writing the next layer's input planes: against the fp32 engine's ACCUM_SPLIT launch on the same inputs (2e-5 of
     the tensor max) and the planes against a split of the fp32 result (bit-identical fp16 pieces)."""
     Rr, S, ks, d = 256, 512, 3, 2
@@ -483,7 +483,7 @@ def test_out_conv_f16x3_matches_fp32_engine(K, x3half, B, T):
 
 @pytest.mark.parametrize('B,T,d,top', [(2, 512, 3, False), (2, 768, 300, True), (8, 6656, 16, False)])
 def test_dgrad_f16x3_matches_fp32_engine(K, x3half, B, T, d, top):
-    """Experimental input gradient of the gate conv (reads AHEAD: x[t + (ks-1-j) d], zero behind the end of a batch row)
+    """fp16x3 input gradient of the gate conv (reads AHEAD: x[t + (ks-1-j) d], zero behind the end of a batch row)
     with the gradient operand lifted by 2^20 into fp16 planes: against the fp32 engine's dgrad launch on the same
     tiny-magnitude inputs (relative 2e-5 of the tensor max)."""
     Rr, ks = 256, 3

@@ -145,7 +145,7 @@ def test_default_width_short_segment(pkg):
 
 @pytest.mark.parametrize('mode', ['1', '2', '3', '4', '5'])
 def test_default_width_gate_f16x3(pkg, monkeypatch, mode):
-    """The same parity run with the experimental fp16x3 gate convs switched on (VQW_GATE_F16X3=1):
+    """The same parity run on the development ladder of the fp16x3 engine (VQW_GATE_F16X3=1..5: fixed scales, no guards):
     the oracle comparison holds at the SAME tolerances as the fp32-MFMA engine (VQ indices bit-exact, logits
     5e-4, losses 2e-5, gradients 5e-3 in relative L2)."""
     monkeypatch.setenv('VQW_GATE_F16X3', mode)   # 1: gate convs, 2: + 1x1 skip/residual convs, 3: skip path as one contraction, 4: + the gate convs' input gradient, 5: + gate backward

@@ -194,7 +194,7 @@ def relu_bn_fwd(x, r, scale, shift):
     L.check(L.lib().vqw_relu_bn_fwd(L.ptr(x), L.ptr(r), L.ptr(scale), L.ptr(shift), B, Cc, T, L.stream()))
 
 
-# ---- experimental: gate conv on the fp16 matrix pipe with two-plane operands (include/vqwave.h)
+# ---- the fp16x3 / bf16 plane engine (include/vqwave.h)
 def _need_planes(t, n_halves, what):
     if t is None or t.dtype != torch.float16 or t.numel() < n_halves:
         raise ValueError('%s must be a float16 tensor with at least %d elements' % (what, n_halves))

@@ -651,8 +651,9 @@ class VQVAE:
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
         dnet_ring, dpre_ring = ws['dnet_ring'], ws['dpre_ring']
-        # Experimental: the gate convs' input gradient on the fp16 matrix pipe.  d(loss)/d(logits) is bounded by 1 / (B T), the
-        # gradient operand is lifted by 2^20 before it is split into fp16 planes (|dpre| < 0.06 assumed, not checked).
+        # Gate backward and the gate convs' input gradient on the plane engine.  Guarded engine: the gradient planes carry
+        # device-side power-of-two scales (slots G and DP[l]); development ladder (VQW_GATE_F16X3=4,5): a fixed lift by 2^20
+        # (d(loss)/d(logits) is bounded by 1 / (B T); |dpre| < 0.06 assumed there, not checked).
         dgrad_x3 = self.dgrad_f16x3 and T % 256 == 0 and R % 256 == 0
         gbwd_x3 = dgrad_x3 and self.gbwd_f16x3 and S % 256 == 0
         full = bool(ws.get('x3_used'))
