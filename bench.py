@@ -381,9 +381,9 @@ def main():
                             "significand bits, products h1h1 + h1h2 + h2h1 on the fp16 MFMA, device-side range guards; "
                             "encoder, head and weight gradients on the fp32 MFMA)")
             rec["config"]["workload"] = rec["config"]["workload"].replace("fp32,", "fp32 (fp16x3 engine),")
-            rec["roofline"].update({"kernel": "gate_f16x3_kernel (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; operands as two fp16 planes, 3 MFMA terms)",
+            rec["roofline"].update({"kernel": "gate_f16x3_kernel<%d-row blocks> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; operands as two fp16 planes, 3 MFMA terms)" % (128 if model.x3_mode_fwd & 2 else 256),
                                     "achieved": 3 * ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * ach / PEAK_F16_MFMA_TFLOPS,
-                                    "fp32_equivalent_tflops": ach, "flop_per_launch": 3 * flops_gate, "traffic": hbm_traffic('round2_gate_f16x3_traffic.json'),
+                                    "fp32_equivalent_tflops": ach, "flop_per_launch": 3 * flops_gate, "traffic": hbm_traffic('round2_gate_f16x3_traffic.json' if model.x3_mode_fwd & 2 else 'round2_gate_f16x3_traffic_256row_blocks.json'),
                                     "whole_step_frac": None,
                                     "whole_step_fp32_equivalent_tflops": 118.14e6 * B * T * a.steps / dt / 1e12})
             rec["engine"] = {"name": "f16x3", "steps_on_engine": model.x3_steps, "steps_repeated_on_fp32": model.x3_fallbacks}
