@@ -1,8 +1,10 @@
 """GPU parity of the assembled model (encoder + VQ + WaveNet decoder, forward + backward +
 Adam/EMA) against the CPU oracle on identical inputs and weights.
 
-Bar: VQ indices and mu-law labels bit-exact; losses rtol 2e-5; logits atol 2e-4; gradients
-within 2e-3 of the per-tensor max (fp32, different summation orders, ~30 layers deep)."""
+Bars (the numbers the asserts below use): VQ indices and mu-law labels bit-exact; z_e 2e-4 and logits 5e-4 of the tensor
+max; losses rtol 2e-5; gradients within 2e-3 of the per-tensor max on the tiny configuration, 5e-3 in relative L2 at
+the reference widths (one relu mask flipped by summation-order noise moves every gradient by up to ~1e-2 at
+B*T = 1024: DESIGN 6, tools/race_diag3.py); parameters / EMA after the Adam step 1e-4."""
 import importlib.util
 import os
 
