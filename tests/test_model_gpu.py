@@ -537,7 +537,7 @@ def test_mfcc_kernel_matches_oracle(pkg):
     K.mfcc(xb, mel, out)
     want = R.mfcc(x[:, :, 0])                                        # [B,frames,13]
     got = out[:, :13].permute(0, 2, 1).cpu()
-    assert float((got - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))      # observed 5.8e-7 of max (tools/mfcc_err.py)
     assert float(out[:, 13:].abs().max()) == 0.0
     assert torch.equal(pkg.ops.mfcc(xb).cpu(), got)                  # the reference-named op (encoder_ops.py:14)
     assert pkg.encoders.Encoder_2019 is pkg.encoders.Encoder2019 and pkg.encoders.Encoder_Magenta is pkg.encoders.EncoderMagenta
