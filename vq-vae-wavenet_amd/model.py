@@ -755,7 +755,11 @@ class VQVAE:
         # ---- skip start + preprocess (wavenet.py:42-55)
         K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
                     C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
-        K.wgrad_gemm(p=net[0], q0=dskip, dw=G['skip0_w'], B=B, T_q=T, T_p=T, Cp=R, Q0=S, taps=[0])
+        if wg_x3:      # both operands already have guard scales (layer-0 input planes, gradient planes)
+            K.f16x3_wgrad(p=net[0], q0=dskip, dw=G['skip0_w'], slab=ws['wslab'], B=B, T=T, Cp=R, Q0=S, taps=[0],
+                          p_scale=sc('X', 0), q0_scale=sc('G'), mode=md)
+        else:
+            K.wgrad_gemm(p=net[0], q0=dskip, dw=G['skip0_w'], B=B, T_q=T, T_p=T, Cp=R, Q0=S, taps=[0])
         K.conv_cin1_wgrad(ws['inputs'], dnet, G['pre_w'], k=self.pre_k, stride=1, offset=-(self.pre_k - 1))
         K.rowsum(dnet, total=G['pre_b'])
         # ---- local condition (wavenet_ops.py:93-101) -> d cond
