@@ -441,6 +441,9 @@ typedef struct vqw_f16x3_wgrad_desc {
     int32_t seg_T;
     int32_t total_o0, total_o1;   /* 0, 0 = all of [0, Q0 + Q1)                                              */
     int32_t mode;           /* VQW_X3_* bits                                                                 */
+    int32_t p_stride;       /* 0 / 1, or 2: p is the input of a stride-2 conv (encoder.py:17-18), row length Tp, read at
+                             * 2 t + tap_shift[j] (shifts of either sign; outside [0, Tp) = zero padding); fp16x3 mode only */
+    int32_t Tp;
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
 

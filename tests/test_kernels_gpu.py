@@ -564,6 +564,51 @@ def test_wgrad_f16x3_matches_fp64(K, B, T, d, Q1, scaled):
     assert float(got_seg[:, Q:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('B,Tq,Tin,pl,scaled', [(2, 416, 832, 1, True), (3, 32, 64, 1, False), (1, 128, 255, 2, True), (8, 1664, 3328, 1, True)])
+def test_wgrad_f16x3_stride2_matches_fp64(K, B, Tq, Tin, pl, scaled):
+    """The encoder's strided convs (encoder.py:17-18, k=5 stride 2, SAME padding): dW[j][c][o] = sum p[b][c][2t + j - pl] q[b][o][t]
+    with both paddings (2t + j - pl < 0 and >= T_in read zero), an odd input length, guard scales, the bias sum riding along;
+    the last case is the benchmark's first 768 -> 768 layer."""
+    Cp = Q0 = 768 if B == 8 else 256
+    gen = torch.Generator().manual_seed(77 + Tq)
+    p = torch.randn(B, Cp, Tin, generator=gen).to(DEV)
+    q = (torch.randn(B, Q0, Tq, generator=gen) * (1e-6 if scaled else 1.0)).to(DEV)
+    taps = [j - pl for j in range(5)]
+    sc = torch.tensor([4.0, 2.0 ** 30] if scaled else [1.0, 1.0], device=DEV)
+    dw0 = torch.randn(5, Cp, Q0, generator=gen).to(DEV) * (1e-6 if scaled else 1.0)
+    slab = torch.empty(256 * 65536, device=DEV)
+    tot0 = torch.randn(Q0, generator=gen).to(DEV) * (1e-4 if scaled else 1.0)
+
+    def run():
+        dw, tot = dw0.clone(), tot0.clone()
+        K.f16x3_wgrad(p=p, q0=q, dw=dw, slab=slab, B=B, T=Tq, Cp=Cp, Q0=Q0, taps=taps, p_scale=sc[0:1], q0_scale=sc[1:2],
+                      p_stride=2, T_p=Tin, q_total=tot)
+        return dw, tot
+    got, tot = run()
+    assert torch.equal(run()[0], got), 'dw is not bitwise reproducible'
+    if B == 8:        # against the fp32 engine's strided wgrad (fp64 over 78 GFLOP is too slow) + fp64 samples
+        ref = dw0.clone()
+        K.wgrad_gemm(p=p, q0=q, dw=ref, B=B, T_q=Tq, T_p=Tin, Cp=Cp, Q0=Q0, p_stride=2, taps=taps)
+        upd = (ref - dw0).abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-5 * upd
+        for (j, c, o) in ((0, 3, 500), (1, 767, 0), (4, 100, 257), (2, 5, 5)):
+            idx = 2 * torch.arange(Tq, device=DEV) + taps[j]
+            ok = (idx >= 0) & (idx < Tin)
+            w64 = (p[:, c, idx.clamp(0, Tin - 1)].double() * ok * q[:, o].double()).sum().item() + dw0[j, c, o].item()
+            assert abs(got[j, c, o].item() - w64) <= 2e-6 * upd, (j, c, o)
+    else:
+        pd = torch.zeros(B, Cp, 2 * Tq + 8, dtype=torch.float64, device=DEV)      # p with its zero padding, index + pl
+        pd[:, :, pl:pl + Tin] = p.double()
+        want = dw0.double().clone()
+        for j in range(5):
+            want[j] += torch.einsum('bct,bot->co', pd[:, :, j:j + 2 * Tq:2], q.double())
+        upd = (want - dw0.double()).abs().max().item()
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2e-6 * upd + 1e-6 * dw0.abs().max().item(), 'max err %.3e of update %.3e' % (err, upd)
+    want_tot = tot0.double() + q.double().sum((0, 2))
+    assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item() + 2e-6 * tot0.abs().max().item()
+
+
 def test_wgrad_f16x3_full_size_matches_fp32_engine(K):
     """The benchmark's shapes (B=8, T=6656: 1664 stage pairs over 42 / 85 K splits): gate-conv and 1x1 weight gradients
     against the fp32 engine's wgrad kernel and fp64 samples."""

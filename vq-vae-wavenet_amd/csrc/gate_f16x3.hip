@@ -112,10 +112,31 @@ __global__ void amax_kernel(const float* __restrict__ x, long rows, int cols, lo
     const size_t n = (size_t)rows * cols;
     float m = 0.0f;
     bool bad = false;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = xb[(i / cols) * ld + (i % cols)];
-        bad |= !(fabsf(v) <= 3.0e38f);
-        m = fmaxf(m, fabsf(v));
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if (ld == cols && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(xb) & 15u) == 0) {      // contiguous: 16 bytes per lane, four requests in flight
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(xb);
+        const size_t n4 = n >> 2;
+        auto fold = [&](const f32x4 v) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = fabsf(v[e]);
+                bad |= !(a <= 3.0e38f);
+                m = fmaxf(m, a);
+            }
+        };
+        size_t i = tid;
+        for (; i + 3 * nthr < n4; i += 4 * nthr) {
+            const f32x4 v0 = __builtin_nontemporal_load(x4 + i), v1 = __builtin_nontemporal_load(x4 + i + nthr);
+            const f32x4 v2 = __builtin_nontemporal_load(x4 + i + 2 * nthr), v3 = __builtin_nontemporal_load(x4 + i + 3 * nthr);
+            fold(v0); fold(v1); fold(v2); fold(v3);
+        }
+        for (; i < n4; i += nthr) fold(__builtin_nontemporal_load(x4 + i));
+    } else {
+        for (size_t i = tid; i < n; i += nthr) {
+            const float v = xb[(i / cols) * ld + (i % cols)];
+            bad |= !(fabsf(v) <= 3.0e38f);
+            m = fmaxf(m, fabsf(v));
+        }
     }
     guard_report(m, bad, 0.0f, amax + blockIdx.y, flag);
 }
@@ -622,6 +643,7 @@ struct WgArgs {
     const float* sq0;
     const float* sq1;
     int B, T, Cp, Q0, Q1, ntaps;
+    int Tp;               // row length of p (= T, or the input length of a stride-2 conv: p index 2 t + shift)
     int shift[VQW_MAX_TAPS];
     int nsplit, pairs_row, pairs_total, n_nt;
     // sums of q over time, formed from the registers that hold q anyway (blocks of the first row tile only):
@@ -648,7 +670,10 @@ __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
 }
 
 // ODD: some tap shift is not a multiple of 4 (compile-time: a branch would cut the loop body into scheduling regions)
-template <bool ODD, bool BF>
+// S2: p is the input of a stride-2 convolution (encoder.py:17-18): dW[j][c][o] += sum p[b][c][2 t + shift_j] q[b][o][t], shifts of
+// either sign, indices outside [0, Tp) are the conv's zero padding.  p is then fetched one float per request (stride 8 bytes
+// between the four of a chunk), each one range-checked on its own through the buffer descriptor.
+template <bool ODD, bool BF, bool S2 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -664,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const float scp = dev_scale(a.sp), scq = dev_scale(from_q1 ? a.sq1 : a.sq0);
     const int T = a.T;
     const int s_begin = (int)((long)split * a.pairs_total / a.nsplit), s_end = (int)((long)(split + 1) * a.pairs_total / a.nsplit);
-    const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(a.p, (unsigned)((size_t)a.B * a.Cp * T * 4));
+    const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(a.p, (unsigned)((size_t)a.B * a.Cp * (S2 ? a.Tp : T) * 4));
     const __amdgpu_buffer_rsrc_t rq = vqw_make_rsrc(qsrc, (unsigned)((size_t)a.B * Qs * T * 4));
 
     // One load instruction of a wave = 32 rows x 32 bytes (lane -> row lane/2, 16-byte half lane%2); chunk n of a
@@ -678,6 +703,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         const int row = g * 32 + rsub;
         const int tq = pt0 + 8 * nn + 4 * hsel;
         rgq[n] = vqw_buf_load4(rq, (int)((((size_t)pb * Qs + oq + row) * T + tq) * 4), 0);
+        if (S2) {
+            const size_t prow = ((size_t)pb * a.Cp + c0 + row) * a.Tp;
+            f32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = 2 * (tq + e) + shift;
+                w[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (idx >= 0 && idx < a.Tp) ? (int)((prow + idx) * 4) : (int)0x80000000, 0, 0));
+            }
+            rgp[n] = w;
+            return;
+        }
         const int tp = tq + shift;                      // shift <= 0: never past the row's end
         const size_t prow = ((size_t)pb * a.Cp + c0 + row) * T;
         // a 16-byte window that straddles t = 0 (only with shifts that are not multiples of 4) is read from t = 0 and moved
@@ -889,7 +925,7 @@ int vqw_f16x3_amax(const float* x, int64_t rows, int cols, int64_t ld, int64_t m
     VQW_CHECK(rows > 0 && cols > 0 && ld >= cols && count >= 1 && count <= 65535, "vqw_f16x3_amax: bad shape (rows=%lld cols=%d ld=%lld count=%d)", (long long)rows, cols, (long long)ld, count);
     const size_t n = (size_t)rows * cols;
     unsigned g = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
-    if (g > 1024) g = 1024;
+    if (g > 2048) g = 2048;
     hipLaunchKernelGGL(amax_kernel, dim3(g, count), dim3(256), 0, (hipStream_t)s_, x, (long)rows, cols, (long)ld, (long)mstride, amax, flag);
     VQW_LAUNCH_CHECK("vqw_f16x3_amax");
     return 0;
@@ -1021,16 +1057,21 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(d.Cp > 0 && d.Cp % 256 == 0 && d.Q0 > 0 && d.Q0 % 256 == 0 && d.Q1 >= 0 && d.Q1 % 256 == 0 && (d.Q1 == 0 || d.q1),
               "vqw_f16x3_wgrad: Cp, Q0, Q1 must be multiples of 256 (Cp=%d Q0=%d Q1=%d)", d.Cp, d.Q0, d.Q1);
     VQW_CHECK(d.ntaps >= 1 && d.ntaps <= VQW_MAX_TAPS, "vqw_f16x3_wgrad: 1..%d taps", VQW_MAX_TAPS);
+    VQW_CHECK(d.p_stride == 0 || d.p_stride == 1 || d.p_stride == 2, "vqw_f16x3_wgrad: p_stride is 1 or 2 (got %d)", d.p_stride);
+    const bool s2 = d.p_stride == 2;
+    const int Tp = s2 ? d.Tp : d.T;
+    VQW_CHECK(!s2 || (Tp > 0 && !(d.mode & 1)), "vqw_f16x3_wgrad: p_stride 2 needs Tp > 0 and the fp16x3 mode (Tp=%d mode=%d)", Tp, d.mode);
     for (int j = 0; j < d.ntaps; ++j)
-        VQW_CHECK(d.tap_shift[j] <= 0 && d.tap_shift[j] > -(1 << 24), "vqw_f16x3_wgrad: tap shifts must be <= 0 (tap %d: %d)", j, d.tap_shift[j]);
-    const size_t pbytes = (size_t)d.B * d.Cp * d.T * 4, qbytes = (size_t)d.B * (d.Q0 > d.Q1 ? d.Q0 : d.Q1) * d.T * 4;
+        VQW_CHECK((s2 ? d.tap_shift[j] < (1 << 24) : d.tap_shift[j] <= 0) && d.tap_shift[j] > -(1 << 24),
+                  "vqw_f16x3_wgrad: tap shifts must be <= 0 unless p_stride is 2 (tap %d: %d)", j, d.tap_shift[j]);
+    const size_t pbytes = (size_t)d.B * d.Cp * Tp * 4, qbytes = (size_t)d.B * (d.Q0 > d.Q1 ? d.Q0 : d.Q1) * d.T * 4;
     VQW_CHECK(pbytes < ((size_t)1 << 31) && qbytes < ((size_t)1 << 31), "vqw_f16x3_wgrad: operands exceed 2 GiB");
     const int lddw = d.lddw > 0 ? d.lddw : d.Q0 + d.Q1;
     VQW_CHECK(lddw >= d.Q0 + d.Q1 && lddw % 4 == 0 && (reinterpret_cast<uintptr_t>(d.dw) & 15u) == 0, "vqw_f16x3_wgrad: dw must be 16-byte aligned, lddw a multiple of 4");
     WgArgs a;
     memset(&a, 0, sizeof(a));
     a.p = d.p; a.q0 = d.q0; a.q1 = d.q1; a.slab = d.slab; a.sp = d.p_scale; a.sq0 = d.q0_scale; a.sq1 = d.q1_scale;
-    a.B = d.B; a.T = d.T; a.Cp = d.Cp; a.Q0 = d.Q0; a.Q1 = d.Q1; a.ntaps = d.ntaps;
+    a.B = d.B; a.T = d.T; a.Cp = d.Cp; a.Q0 = d.Q0; a.Q1 = d.Q1; a.ntaps = d.ntaps; a.Tp = Tp;
     for (int j = 0; j < d.ntaps; ++j) a.shift[j] = d.tap_shift[j];
     a.pairs_row = d.T / 32; a.pairs_total = d.B * a.pairs_row;
     a.n_nt = (d.Q0 + d.Q1) / 256;
@@ -1054,7 +1095,7 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     typedef void (*kfn_t)(WgArgs);
     const kfn_t ktab[4] = {wgrad_f16x3_kernel<false, false>, wgrad_f16x3_kernel<true, false>, wgrad_f16x3_kernel<false, true>,
                            wgrad_f16x3_kernel<true, true>};
-    const kfn_t kfn = ktab[(odd ? 1 : 0) + 2 * (d.mode & 1)];
+    const kfn_t kfn = s2 ? wgrad_f16x3_kernel<false, false, true> : ktab[(odd ? 1 : 0) + 2 * (d.mode & 1)];
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
     hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);

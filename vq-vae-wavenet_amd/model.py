@@ -793,6 +793,13 @@ class VQVAE:
         K.conv_gemm(x0=dz, w=Tt['enc_w6'], out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
+        # the long layers' weight gradients on the fp16x3 engine too (when the decoder's ran there this step): operands split in
+        # registers with exact power-of-two scales of THIS step's tensors (max-abs pass, then 2^13 / amax), bias sums riding along
+        enc_x3 = ('wslab' in ws and bool(ws.get('x3_used')) and self.x3_guard and not self.bf16 and F % 256 == 0
+                  and os.environ.get('VQW_ENC_WGRAD_X3', '1') != '0')
+        if enc_x3 and 'enc_amax' not in ws:
+            ws['enc_amax'] = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            ws['enc_scale'] = torch.ones(2, device=self.dev)
         for i in range(5, -1, -1):
             dX, r = ws['dX'][i], ws['r'][i]
             Ti = ws['Tl'][i]
@@ -807,12 +814,21 @@ class VQVAE:
             with torch.cuda.stream(side):                            # weight / bias gradients: nothing downstream waits
                 if side is not main:
                     side.wait_event(ready)
-                K.rowsum(dX, total=G['enc_b'][i])
-                if i == 0:
-                    K.conv_cin1_wgrad(x, dX, G['enc_w0'], k=5, stride=2, offset=-pl)
+                if i > 0 and enc_x3 and Ti % 32 == 0 and B * F * Tin * 4 < (1 << 31):
+                    ea, es = ws['enc_amax'], ws['enc_scale']
+                    K.f16x3_amax(ws['X'][i - 1], ea[0:1])
+                    K.f16x3_amax(dX, ea[1:2])
+                    K.f16x3_update_scales(ea, es, target_exp=13)
+                    K.f16x3_wgrad(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], slab=ws['wslab'], B=B, T=Ti, Cp=F, Q0=F,
+                                  taps=[j - pl for j in range(5)], p_scale=es[0:1], q0_scale=es[1:2], p_stride=2, T_p=Tin,
+                                  q_total=G['enc_b'][i], mode=0)
                 else:
-                    K.wgrad_gemm(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], B=B, T_q=Ti, T_p=Tin, Cp=F, Q0=F, p_stride=2,
-                                 taps=[j - pl for j in range(5)])
+                    K.rowsum(dX, total=G['enc_b'][i])
+                    if i == 0:
+                        K.conv_cin1_wgrad(x, dX, G['enc_w0'], k=5, stride=2, offset=-pl)
+                    else:
+                        K.wgrad_gemm(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], B=B, T_q=Ti, T_p=Tin, Cp=F, Q0=F, p_stride=2,
+                                     taps=[j - pl for j in range(5)])
             if i == 0:
                 break
             # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
