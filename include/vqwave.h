@@ -322,6 +322,7 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
  *                      block height).  No effect on the other entry points.                                          */
 #define VQW_X3_BF16 1
 #define VQW_X3_HALF_BLOCKS 2
+#define VQW_X3_S2D 4          /* vqw_f16x3_split_activations only: space-to-depth planes for vqw_f16x3_strided_conv */
 
 /* Range guards.  The leading plane of scale * x must stay inside fp16 (|.| <= 65504).  Scales are powers of two held in
  * DEVICE memory, chosen from measured max-abs values with no host round trip:
@@ -418,6 +419,28 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
  * [0, T) are zero).  `slab` is scratch: tiles * nsplit * 65536 floats (tiles = ntaps * Cp/256 * (Q0+Q1)/256; nsplit 0 =
  * CUs / tiles): partial tiles are summed in a fixed order by a second launch -- dw is bitwise reproducible (q_total /
  * q_seg are met by fp32 atomics).                                                                                  */
+/* The encoder's stride-2 convs on the fp16x3 engine (encoder.py:17-18: tf.layers.conv1d(768, 5, strides 2, 'same') -> relu ->
+ * batch_normalization in inference mode, and TF's Conv2DBackpropInput of it).  Kernel w[ks][Cin][M] as planes
+ * (vqw_f16x3_pack_weights, K = ks * Cin); for the input gradient the transposed kernel wt[ks][Cout][Cin] with Cin := Cout, M := Cin.
+ *   dgrad = 0: out[b][m][t] = bn_scale[m] * relu(sum_j sum_c w[j][c][m] x[b][c][2t + j - pad_left] + bias[m]) + bn_shift[m],
+ *              t < T; xp = vqw_f16x3_split_activations(x [B][Cin][2T], mode | VQW_X3_S2D); save_r (or NULL) gets the relu output
+ *   dgrad = 1: out[b][m][u] (u < 2T) = sum_{j, t: 2t + j - pad_left = u} sum_o wt[j][o][m] dy[b][o][t]; xp = plain planes of dy [B][Cin][T]
+ * B * T % 256 == 0, Cin % 32 == 0, M % 128 == 0.  Results are scaled by w_scale_inv / (x_scale[0] * w_scale[0]).           */
+typedef struct vqw_f16x3_sconv_desc {
+    const void* xp;
+    const void* wp;
+    const float* bias;      /* [M] or NULL (forward)                                                        */
+    const float* bn_scale;  /* [M] or NULL (forward)                                                        */
+    const float* bn_shift;
+    float* out;
+    float* save_r;          /* [B][M][T] or NULL (forward)                                                  */
+    const float* x_scale;   /* device scalars (or NULL = 1): the scales the operand planes were made with   */
+    const float* w_scale;
+    float w_scale_inv;
+    int32_t B, T, Cin, M, ks, pad_left, relu, dgrad;
+} vqw_f16x3_sconv_desc;
+int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* d, vqw_stream_t s);
+
 typedef struct vqw_f16x3_wgrad_desc {
     const float* p;
     const float* q0;

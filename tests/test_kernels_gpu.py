@@ -609,6 +609,63 @@ def test_wgrad_f16x3_stride2_matches_fp64(K, B, Tq, Tin, pl, scaled):
     assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item() + 2e-6 * tot0.abs().max().item()
 
 
+@pytest.mark.parametrize('B,Tout,Cin,M', [(2, 128, 128, 128), (1, 256, 128, 256), (8, 96, 128, 128), (8, 1664, 768, 768)])
+def test_strided_conv_f16x3_forward_and_input_gradient(K, B, Tout, Cin, M):
+    """vqw_f16x3_strided_conv against torch's conv1d / its autograd in fp64 (encoder.py:17-18: k=5, stride 2, SAME = one zero in
+    front, two behind; bias -> relu -> BatchNorm affine): column tiles that straddle batch rows (T = 96, 1664), both paddings,
+    operand scales on the device, the saved relu output; the last case is the benchmark's first 768 -> 768 layer (against the
+    fp32 engine's kernels there)."""
+    import torch.nn.functional as Fn
+    ks, pl, Tin = 5, 1, 2 * Tout
+    gen = torch.Generator().manual_seed(31 + Tout)
+    x = torch.randn(B, Cin, Tin, generator=gen).to(DEV)
+    w = (torch.randn(ks, Cin, M, generator=gen) * 0.05).to(DEV)
+    bias, bsc, bsh = (torch.randn(M, generator=gen).to(DEV) * s_ for s_ in (0.5, 1.0, 0.3))
+    sc = torch.tensor([8.0, 256.0, 2.0 ** 22], device=DEV)                 # x, w, dy
+    xp = torch.empty(2 * B * Cin * Tin, dtype=torch.float16, device=DEV)
+    wp = torch.empty(2 * ks * Cin * M, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(x, xp, B, Cin, Tin, scale_dev=sc[0:1], mode=K.X3_S2D)
+    K.f16x3_pack_weights(w, wp, ks * Cin, M, M, 1.0, scale_dev=sc[1:2], mode=0)
+    out, r = torch.empty(B, M, Tout, device=DEV), torch.empty(B, M, Tout, device=DEV)
+    K.f16x3_strided_conv(xp=xp, wp=wp, out=out, save_r=r, B=B, T=Tout, Cin=Cin, M=M, ks=ks, pad_left=pl, bias=bias, bn_scale=bsc,
+                         bn_shift=bsh, relu=True, x_scale=sc[0:1], w_scale=sc[1:2])
+    big = B * Cin * Tin > (1 << 22)
+    if big:
+        want, want_r = torch.empty_like(out), torch.empty_like(r)
+        K.conv_gemm(x0=x, w=w, bias=bias, out0=want, save0=want_r, scale=bsc, shift=bsh, B=B, T_in=Tin, T_out=Tout, M=M, C0=Cin,
+                    in_stride=2, taps=[j - pl for j in range(ks)], out_relu=True)
+    else:
+        y = Fn.conv1d(Fn.pad(x.double(), (pl, ks - 2 - pl)), w.permute(2, 1, 0).double(), bias.double(), stride=2)
+        want_r = torch.relu(y)
+        want = bsc.double()[None, :, None] * want_r + bsh.double()[None, :, None]
+    tol = 2e-5 if big else 3e-6
+    assert (r.double() - want_r.double()).abs().max().item() <= tol * want_r.abs().max().item()
+    assert (out.double() - want.double()).abs().max().item() <= tol * want.abs().max().item()
+    # input gradient: dy [B][M][Tout] -> dx [B][Cin][Tin] through the transposed kernel wt[j][m][c]
+    dy = (torch.randn(B, M, Tout, generator=gen) * 1e-4).to(DEV)
+    wt = w.permute(0, 2, 1).contiguous()
+    dyp = torch.empty(2 * B * M * Tout, dtype=torch.float16, device=DEV)
+    wtp = torch.empty(2 * ks * M * Cin, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(dy, dyp, B, M, Tout, scale_dev=sc[2:3], mode=0)
+    K.f16x3_pack_weights(wt, wtp, ks * M, Cin, Cin, 1.0, scale_dev=sc[1:2], mode=0)
+    dx = torch.full((B, Cin, Tin), float('nan'), device=DEV)
+    K.f16x3_strided_conv(xp=dyp, wp=wtp, out=dx, B=B, T=Tout, Cin=M, M=Cin, ks=ks, pad_left=pl, dgrad=True, x_scale=sc[2:3],
+                         w_scale=sc[1:2])
+    if big:
+        want_dx = torch.empty_like(dx)
+        for p in (0, 1):
+            j0 = (p + pl) % 2
+            js = list(range(j0, ks, 2))
+            K.conv_gemm(x0=dy, w=wt[j0:], w_tap_stride=2 * M * Cin, out0=want_dx, B=B, T_in=Tout, T_out=(Tin - p + 1) // 2, M=Cin,
+                        C0=M, taps=[(p + pl - j) // 2 for j in js], out_tstride=2, out_toffset=p, T_store=Tin)
+    else:
+        xd = x.double().requires_grad_(True)
+        y = Fn.conv1d(Fn.pad(xd, (pl, ks - 2 - pl)), w.permute(2, 1, 0).double(), None, stride=2)
+        want_dx, = torch.autograd.grad(y, xd, dy.double())
+    assert torch.isfinite(dx).all()
+    assert (dx.double() - want_dx.double()).abs().max().item() <= tol * want_dx.abs().max().item()
+
+
 def test_wgrad_f16x3_full_size_matches_fp32_engine(K):
     """The benchmark's shapes (B=8, T=6656: 1664 stage pairs over 42 / 85 K splits): gate-conv and 1x1 weight gradients
     against the fp32 engine's wgrad kernel and fp64 samples."""

@@ -75,6 +75,15 @@ class F16x3OutDesc(C.Structure):
         ('x_scale', _fp), ('w_scale', _fp), ('out_scale', _fp), ('out_amax', _fp), ('flag', _fp), ('mode', C.c_int32),
     ]
 
+class F16x3SconvDesc(C.Structure):
+    _fields_ = [
+        ('xp', _fp), ('wp', _fp), ('bias', _fp), ('bn_scale', _fp), ('bn_shift', _fp), ('out', _fp), ('save_r', _fp),
+        ('x_scale', _fp), ('w_scale', _fp), ('w_scale_inv', C.c_float),
+        ('B', C.c_int32), ('T', C.c_int32), ('Cin', C.c_int32), ('M', C.c_int32), ('ks', C.c_int32), ('pad_left', C.c_int32),
+        ('relu', C.c_int32), ('dgrad', C.c_int32),
+    ]
+
+
 class F16x3WgradDesc(C.Structure):
     _fields_ = [
         ('p', _fp), ('q0', _fp), ('q1', _fp), ('dw', _fp), ('slab', _fp), ('slab_floats', C.c_int64),
@@ -135,6 +144,7 @@ SIGNATURES = {
     'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _i, _fp]),
     'vqw_f16x3_out_conv': (_i, [C.POINTER(F16x3OutDesc), _fp]),
     'vqw_f16x3_wgrad': (_i, [C.POINTER(F16x3WgradDesc), _fp]),
+    'vqw_f16x3_strided_conv': (_i, [C.POINTER(F16x3SconvDesc), _fp]),
 }
 
 _lib = None

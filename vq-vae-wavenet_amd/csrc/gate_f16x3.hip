@@ -77,9 +77,11 @@ __device__ __forceinline__ void guard_report(float m, bool bad, float ps, unsign
 }
 
 // x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16 of scale * scale_dev[0] * x
+// s2d (the input of a stride-2 conv; T even): planes [2][2 C/8][B*T/2][8], sample t = 2 t' + r of channel c in chunk block r
+// (chunks r C/8 ..), row b T/2 + t' -- the strided conv then reads whole consecutive rows per tap (LoopGeom, TAB)
 template <bool BF>
 __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int B, int C, int T, float scale, int kc0, int KC,
-                                 const float* __restrict__ scale_dev, unsigned* amax, int* flag) {
+                                 const float* __restrict__ scale_dev, unsigned* amax, int* flag, int s2d) {
     const size_t NB = (size_t)B * T;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < NB * (C / 8);
@@ -100,8 +102,15 @@ __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict_
         }
         uint4 p0, p1;
         split8<BF>(v, p0, p1);
-        planes[(size_t)(kc0 + kc) * NB + row] = p0;
-        if (!BF) planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
+        if (s2d) {
+            const size_t NH = NB / 2, r2 = (size_t)b * (T / 2) + t / 2;
+            const int kcs = (t & 1) * (C / 8) + kc;
+            planes[(size_t)kcs * NH + r2] = p0;
+            if (!BF) planes[((size_t)(C / 4) + kcs) * NH + r2] = p1;
+        } else {
+            planes[(size_t)(kc0 + kc) * NB + row] = p0;
+            if (!BF) planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
+        }
     }
     guard_report(m, bad, sc, amax, flag);
 }
@@ -125,10 +134,12 @@ __global__ void amax_kernel(const float* __restrict__ x, long rows, int cols, lo
             }
         };
         size_t i = tid;
-        for (; i + 3 * nthr < n4; i += 4 * nthr) {
-            const f32x4 v0 = __builtin_nontemporal_load(x4 + i), v1 = __builtin_nontemporal_load(x4 + i + nthr);
-            const f32x4 v2 = __builtin_nontemporal_load(x4 + i + 2 * nthr), v3 = __builtin_nontemporal_load(x4 + i + 3 * nthr);
-            fold(v0); fold(v1); fold(v2); fold(v3);
+        for (; i + 7 * nthr < n4; i += 8 * nthr) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(x4 + i + u * nthr);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fold(v[u]);
         }
         for (; i < n4; i += nthr) fold(__builtin_nontemporal_load(x4 + i));
     } else {
@@ -138,7 +149,19 @@ __global__ void amax_kernel(const float* __restrict__ x, long rows, int cols, lo
             m = fmaxf(m, fabsf(v));
         }
     }
-    guard_report(m, bad, 0.0f, amax + blockIdx.y, flag);
+    // one atomic per BLOCK (thousands of waves hitting one address serialise in L2: 8 k wave-level atomics cost ~70 us)
+    __shared__ float smax[4];
+    __shared__ int sbad[4];
+    const float wm = wave_max(m);
+    const bool wbad = __any(bad);
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = wm; sbad[threadIdx.x >> 6] = wbad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bits = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+        unsigned* dst = amax + blockIdx.y;
+        if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+        if (flag && (sbad[0] | sbad[1] | sbad[2] | sbad[3])) atomicOr(flag, 1);
+    }
 }
 
 // scale[i] = 2^(target_exp - 1 - floor(log2(amax[i]))): amax * scale in [2^(target_exp-1), 2^target_exp); a slot that saw
@@ -232,6 +255,12 @@ struct LoopGeom {
     int M, Cin, ks, dilation, NB, m_row0, n0, t0;
     int xKC, xkc0;   // chunks per plane of xp and the first chunk of this contraction (planes may hold more channels)
     int dir, T;      // dir > 0: tap j reads x[t - (ks-1-j) d] (causal conv); dir < 0: x[t + (ks-1-j) d] (its input gradient)
+    // TAB (stride-2 convs, encoder.py:17-18): the loop's tap i is tap j = tj0 + tjstep * i of a kernel with `wks` taps (the weight
+    // planes hold all of them); with e = j - toff it reads activation row t - tsgn * (e >> 1) of chunk block (ts2d ? e & 1 : 0):
+    //   forward over space-to-depth planes (chunk block = parity of the input sample): tsgn = -1, toff = pad_left, ts2d = 1;
+    //   input gradient of output parity r: tj0 = (r + pad_left) & 1, tjstep = 2, toff = r + pad_left, tsgn = +1, ts2d = 0.
+    // n0 may lie anywhere in the flat (batch, time) row space: rows outside the lane's own batch row read as zero.
+    int wks, tj0, tjstep, toff, tsgn, ts2d;
 };
 
 // acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: MR x 2 accumulator tiles per wave, operands through
@@ -257,14 +286,14 @@ template <int MR> struct X3Shape {
     static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
     static constexpr int DEPTH = MR == 8 ? 2 : 1;                 // stages of requests in flight
 };
-template <bool BF, int MR>
+template <bool BF, int MR, bool TAB = false>
 __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem, const LoopGeom& g, int wv, int lane) {
     constexpr int NP = BF ? 1 : 2;        // planes per operand
     constexpr int NA = MR * NP / 4, NBP = 2 * NP;      // weight / activation pieces a wave moves per step
     if (MR == 4) x3_stagger(VQW_X3_STAGGER);
     constexpr int NSTG_ = X3Shape<MR>::NSTAGE, STGB = X3Shape<MR>::STAGE_BYTES, BOFF = MR * 2 * 1024, DEPTH = X3Shape<MR>::DEPTH;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int KCA = g.ks * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
+    const int KCA = (TAB ? g.wks : g.ks) * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
     const int nsteps = g.ks * spt;
     const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(g.wp, (unsigned)((size_t)2 * KCA * g.M * 16));
     const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(g.xp, (unsigned)((size_t)2 * g.xKC * g.NB * 16));
@@ -282,18 +311,21 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem,
         const int q = wv * NBP + i, tile = q / NP, p = q % NP;
         pieceB[i] = tile * 2 + p;
         voffB[i] = ((p * g.xKC + g.xkc0 + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
-        trow[i] = g.t0 + tile * 32 + l31;                    // time of this lane's activation row
+        trow[i] = TAB ? (g.n0 + tile * 32 + l31) % g.T : g.t0 + tile * 32 + l31;      // time of this lane's activation row
     }
     f32x4 rgA[NA + NBP], rgB[NA + NBP];
     auto rissue = [&](int s, f32x4 (&rg)[NA + NBP]) {
-        const int j = s / spt, kc = (s - j * spt) * 2;
-        const int shift = (g.ks - 1 - j) * g.dilation * (g.dir < 0 ? -1 : 1);   // rows before / behind the batch row read as zero
+        const int ji = s / spt, kc = (s - ji * spt) * 2;
+        const int j = TAB ? g.tj0 + g.tjstep * ji : ji;
+        const int e_ = TAB ? j - g.toff : 0;
+        const int shift = TAB ? g.tsgn * (e_ >> 1) : (g.ks - 1 - j) * g.dilation * (g.dir < 0 ? -1 : 1);   // rows before / behind the batch row read as zero
+        const int kcx = TAB ? kc + (g.ts2d ? (e_ & 1) * KCB : 0) : kc;
 #pragma unroll
         for (int i = 0; i < NA; ++i) rg[i] = vqw_buf_load4(ra, voffA[i] + (j * KCB + kc) * g.M * 16, 0);
 #pragma unroll
         for (int i = 0; i < NBP; ++i) {
             const int tr = trow[i] - shift;
-            const int vb = (tr >= 0 && tr < g.T) ? voffB[i] + (kc * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
+            const int vb = (tr >= 0 && tr < g.T) ? voffB[i] + (kcx * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
             rg[NA + i] = vqw_buf_load4(rb, vb, 0);
         }
     };
@@ -622,6 +654,86 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
 }
 
 
+// The encoder's stride-2 convs (encoder.py:17-18: conv k=5 stride 2 SAME -> relu -> BatchNorm affine) and their input
+// gradients on the same main loop (LoopGeom TAB).  128-row blocks (two per CU), 256 flat (batch, time) columns per block;
+// a column tile may straddle two batch rows (T = 1664 is not a multiple of 256): every lane carries its own (batch, time).
+//   forward:  out[b][m][t] = bn_scale[m] * relu(sum_j sum_c W[j][c][m] x[b][c][2t + j - pad] + bias[m]) + bn_shift[m],
+//             x as space-to-depth planes (split_act_kernel, s2d); relu output optionally saved for the backward pass
+//   dgrad:    dx[b][m][2u + r] = sum_{j = r + pad (mod 2)} sum_o Wt[j][o][m] dy[b][o][u + (r + pad - j) / 2], both parities
+//             r by the same block one after the other (their stores interleave in the same lines)
+struct SconvArgs {
+    vqw_f16x3_sconv_desc d;
+    int NB;
+};
+__global__ __launch_bounds__(256, 2) void sconv_f16x3_kernel(const SconvArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int MR = 4, HB = 32 * MR;
+    const vqw_f16x3_sconv_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int T = d.T, M = d.M;
+    const int n_mt = M / HB;
+    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
+    const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
+    int bcol[2], tcol[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 64 * wv + 32 * j + l31;
+        bcol[j] = n / T;
+        tcol[j] = n - bcol[j] * T;
+    }
+    f32x16 acc[MR][2];
+    LoopGeom g;
+    g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = d.Cin; g.dilation = 1; g.NB = a.NB; g.xkc0 = 0; g.dir = 1; g.T = T;
+    g.m_row0 = mt * HB; g.n0 = n0; g.t0 = 0; g.wks = d.ks;
+    if (!d.dgrad) {
+        g.ks = d.ks; g.xKC = 2 * d.Cin / 8; g.tj0 = 0; g.tjstep = 1; g.toff = d.pad_left; g.tsgn = -1; g.ts2d = 1;
+        f16x3_mainloop<false, MR, true>(acc, smem, g, wv, lane);
+        const bool hb = d.bias != nullptr, hs = d.bn_scale != nullptr, sv = d.save_r != nullptr;
+        const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);
+        const float* sp = hs ? d.bn_scale : reinterpret_cast<const float*>(d.wp);
+        const float* hp = hs ? d.bn_shift : reinterpret_cast<const float*>(d.wp);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int m0 = mt * HB + 32 * i + 8 * v4 + 4 * lhi;      // first of this lane's four rows
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bv = bp[hb ? m0 + e : 0], sc = sp[hs ? m0 + e : 0], sh = hp[hs ? m0 + e : 0];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const size_t off = ((size_t)bcol[j] * M + m0 + e) * T + tcol[j];
+                        float y = acc[i][j][v4 * 4 + e] * winv + (hb ? bv : 0.0f);
+                        if (d.relu) y = fmaxf(y, 0.0f);
+                        if (sv) d.save_r[off] = y;
+                        d.out[off] = hs ? sc * y + sh : y;
+                    }
+                }
+            }
+    } else {
+        g.xKC = d.Cin / 8; g.tjstep = 2; g.tsgn = 1; g.ts2d = 0;
+        for (int r = 0; r < 2; ++r) {
+            g.tj0 = (r + d.pad_left) & 1; g.toff = r + d.pad_left;
+            g.ks = (d.ks - g.tj0 + 1) / 2;                       // taps of this parity (>= 1 for ks >= 2)
+            if (r) __syncthreads();                              // the first run's last stage is still being read
+            f16x3_mainloop<false, MR, true>(acc, smem, g, wv, lane);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const int m0 = mt * HB + 32 * i + 8 * v4 + 4 * lhi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            d.out[((size_t)bcol[j] * M + m0 + e) * (2 * T) + 2 * tcol[j] + r] = acc[i][j][v4 * 4 + e] * winv;
+                }
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients on the fp16 matrix pipe:  dW[j][c][o] += sum_{b,t} p[b][c][t + shift_j] * q[b][o][t]
 // (TF Conv2DBackpropFilter of conv1d_v2, wavenet_ops.py:83-86; q = [q0; q1] along o).
@@ -924,8 +1036,8 @@ int vqw_f16x3_amax(const float* x, int64_t rows, int cols, int64_t ld, int64_t m
     VQW_CHECK(x && amax, "vqw_f16x3_amax: null pointer");
     VQW_CHECK(rows > 0 && cols > 0 && ld >= cols && count >= 1 && count <= 65535, "vqw_f16x3_amax: bad shape (rows=%lld cols=%d ld=%lld count=%d)", (long long)rows, cols, (long long)ld, count);
     const size_t n = (size_t)rows * cols;
-    unsigned g = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
-    if (g > 2048) g = 2048;
+    unsigned g = (unsigned)((n + 256 * 32 - 1) / (256 * 32));
+    if (g > 512) g = 512;
     hipLaunchKernelGGL(amax_kernel, dim3(g, count), dim3(256), 0, (hipStream_t)s_, x, (long)rows, cols, (long)ld, (long)mstride, amax, flag);
     VQW_LAUNCH_CHECK("vqw_f16x3_amax");
     return 0;
@@ -947,11 +1059,13 @@ int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int 
     if (KC <= 0) { KC = C / 8; kc0 = 0; }
     VQW_CHECK(kc0 >= 0 && kc0 + C / 8 <= KC, "vqw_f16x3_split_activations: bad chunk range (kc0=%d KC=%d)", kc0, KC);
     const size_t n = (size_t)B * T * (C / 8);
-    VQW_CHECK(mode >= 0 && mode <= 3, "vqw_f16x3_split_activations: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS");
+    VQW_CHECK(mode >= 0 && mode <= 7, "vqw_f16x3_split_activations: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS | VQW_X3_S2D");
+    const int s2d = (mode & VQW_X3_S2D) ? 1 : 0;
+    VQW_CHECK(!s2d || (T % 2 == 0 && kc0 == 0 && KC == C / 8), "vqw_f16x3_split_activations: space-to-depth planes need an even T and the whole plane (T=%d kc0=%d)", T, kc0);
     if (mode & 1) hipLaunchKernelGGL(split_act_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
-                                 scale_dev, amax, flag);
+                                 scale_dev, amax, flag, s2d);
     else hipLaunchKernelGGL(split_act_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, (uint4*)planes, B, C, T, scale, kc0, KC,
-                            scale_dev, amax, flag);
+                            scale_dev, amax, flag, s2d);
     VQW_LAUNCH_CHECK("vqw_f16x3_split_activations");
     return 0;
 }
@@ -1045,6 +1159,30 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
     const int blocks = (d.R / (half ? 64 : 128)) * (a.NB / 256);
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_gate_conv");
+    return 0;
+}
+
+int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(dp, "vqw_f16x3_strided_conv: null descriptor");
+    const vqw_f16x3_sconv_desc& d = *dp;
+    VQW_CHECK(d.xp && d.wp && d.out, "vqw_f16x3_strided_conv: null operand");
+    VQW_CHECK(d.B > 0 && d.T > 0 && ((long)d.B * d.T) % 256 == 0, "vqw_f16x3_strided_conv: B * T must be a multiple of 256 (B=%d T=%d)", d.B, d.T);
+    VQW_CHECK(d.Cin >= 64 && d.Cin % 32 == 0 && d.M > 0 && d.M % 128 == 0, "vqw_f16x3_strided_conv: Cin %% 32, M %% 128 (Cin=%d M=%d)", d.Cin, d.M);
+    VQW_CHECK(d.ks >= 2 && d.ks <= 8 && d.pad_left >= 0 && d.pad_left < d.ks, "vqw_f16x3_strided_conv: 2..8 taps, 0 <= pad_left < ks (ks=%d pad_left=%d)", d.ks, d.pad_left);
+    VQW_CHECK(!d.bn_scale || d.bn_shift, "vqw_f16x3_strided_conv: bn_scale needs bn_shift");
+    VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_strided_conv: w_scale_inv must be positive");
+    const size_t xbytes = (size_t)2 * (d.dgrad ? 1 : 2) * (d.Cin / 8) * d.B * d.T * 16, obytes = (size_t)d.B * d.M * d.T * (d.dgrad ? 2 : 1) * 4;
+    VQW_CHECK(xbytes < ((size_t)1 << 31) && obytes < ((size_t)1 << 31) && (size_t)2 * d.ks * (d.Cin / 8) * d.M * 16 < ((size_t)1 << 31),
+              "vqw_f16x3_strided_conv: operands exceed 2 GiB");
+    SconvArgs a;
+    a.d = d;
+    a.NB = d.B * d.T;
+    const int lds = X3Shape<4>::LDS_BYTES;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sconv_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return vqw_set_error("vqw_f16x3_strided_conv: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL(sconv_f16x3_kernel, dim3((d.M / 128) * (a.NB / 256)), dim3(256), lds, st, a);
+    VQW_LAUNCH_CHECK("vqw_f16x3_strided_conv");
     return 0;
 }
 

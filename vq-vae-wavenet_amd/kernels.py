@@ -201,7 +201,7 @@ def _need_planes(t, n_halves, what):
     L.require_cuda(t)
 
 
-X3_BF16, X3_HALF_BLOCKS = 1, 2      # VQW_X3_* mode bits of include/vqwave.h
+X3_BF16, X3_HALF_BLOCKS, X3_S2D = 1, 2, 4      # VQW_X3_* mode bits of include/vqwave.h
 
 
 def x3_mode(mode=None, bf16=False):
@@ -309,6 +309,30 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     d.out_amax, d.flag = _slot(out_amax, 'out_amax', torch.int32), _slot(flag, 'flag', torch.int32)
     d.mode = mode
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
+
+
+def f16x3_strided_conv(*, xp, wp, out, B, T, Cin, M, ks, pad_left, w_scale_inv=1.0, bias=None, bn_scale=None, bn_shift=None,
+                       save_r=None, relu=False, dgrad=False, x_scale=None, w_scale=None):
+    """vqw_f16x3_strided_conv: a stride-2 conv (SAME padding, pad_left zeros in front) -> bias -> relu -> BatchNorm affine over
+    space-to-depth planes of x [B][Cin][2T] (out [B][M][T]), or with dgrad its input gradient from the planes of dy [B][Cin][T]
+    (out [B][M][2T]; wp = planes of the transposed kernel)."""
+    _need_planes(xp, 2 * Cin * B * T * (1 if dgrad else 2), 'xp')
+    _need_planes(wp, 2 * ks * Cin * M, 'wp')
+    _need(out, B * M * T * (2 if dgrad else 1), 'out')
+    for name, t in (('bias', bias), ('bn_scale', bn_scale), ('bn_shift', bn_shift)):
+        if t is not None:
+            _need(t, M, name)
+    if save_r is not None:
+        _need(save_r, B * M * T, 'save_r')
+    d = L.F16x3SconvDesc()
+    d.xp, d.wp, d.out = xp.data_ptr(), wp.data_ptr(), out.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.bn_scale = None if bn_scale is None else bn_scale.data_ptr()
+    d.bn_shift = None if bn_shift is None else bn_shift.data_ptr()
+    d.save_r = None if save_r is None else save_r.data_ptr()
+    d.x_scale, d.w_scale, d.w_scale_inv = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale'), float(w_scale_inv)
+    d.B, d.T, d.Cin, d.M, d.ks, d.pad_left, d.relu, d.dgrad = B, T, Cin, M, ks, pad_left, int(bool(relu)), int(bool(dgrad))
+    L.check(L.lib().vqw_f16x3_strided_conv(C.byref(d), L.stream()))
 
 
 def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,

@@ -336,6 +336,13 @@ class VQVAE:
         ws['labels'] = torch.empty(B, T, dtype=torch.int32, device=dev)
         if self.enc == '64':
             ws['X'] = [e(B, F, t) for t in ws['Tl']]      # BN outputs of encoder layers 0..5
+            if self.x3_guard and not self.bf16 and F % 256 == 0:      # fp16x3 engine for layers 1..3 (_enc_x3_layers)
+                ws['eplanes'] = torch.empty(2 * B * F * ws['Tl'][0], dtype=torch.float16, device=dev)   # planes of one layer's operand
+                ws['ewp'] = torch.empty(3, 2 * 5 * F * F, dtype=torch.float16, device=dev)
+                ws['enc_amax'] = torch.zeros(8, dtype=torch.int32, device=dev)
+                ws['enc_scale'] = torch.ones(8, device=dev)
+                if train:
+                    ws['ewtp'] = torch.empty(3, 2 * 5 * F * F, dtype=torch.float16, device=dev)
             if train:
                 ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
                 ws['y6'] = e(B, D, Tz)
@@ -411,11 +418,26 @@ class VQVAE:
         K.conv_cin1_fwd(x, P['enc_w0'], P['enc_b'][0], ws['X'][0], k=5, stride=2, offset=-pl, relu=True,
                         scale=sc[:F], shift=sh[:F], save_r=ws['r'][0] if save else None)
         Tin = ws['Tl'][0]
+        # the long strided layers on the fp16x3 engine (space-to-depth planes): exact power-of-two scales from a
+        # max-abs pass over this step's tensors; a non-finite value raises the step's range flag (-> fp32 repeat)
+        ex3 = ws['enc_x3'] = self._enc_x3_layers(ws)
+        if ex3:
+            ea, es, flag = ws['enc_amax'], ws['enc_scale'], self.x3_flag
+            K.f16x3_amax(P['enc_w'][:3], ea[0:1], flag=flag)
+            K.f16x3_update_scales(ea[0:1], es[0:1], target_exp=14, flag=flag)
+            K.f16x3_pack_weights(P['enc_w'], ws['ewp'], 5 * F, F, F, 1.0, count=3, scale_dev=es[0:1], mode=0)
         for i in range(1, 6):
             Tout = ws['Tl'][i]
             pl, _ = same_pads(Tin, 5, 2)
             nsplit = self._short_layer_split(F, Tout, B)
-            if nsplit > 1:
+            if i in ex3:
+                K.f16x3_amax(ws['X'][i - 1], ea[i:i + 1], flag=flag)
+                K.f16x3_update_scales(ea[i:i + 1], es[i:i + 1], target_exp=13, flag=flag)
+                K.f16x3_split_activations(ws['X'][i - 1], ws['eplanes'], B, F, Tin, scale_dev=es[i:i + 1], mode=K.X3_S2D)
+                K.f16x3_strided_conv(xp=ws['eplanes'], wp=ws['ewp'][i - 1], out=ws['X'][i], save_r=ws['r'][i] if save else None,
+                                     B=B, T=Tout, Cin=F, M=F, ks=5, pad_left=pl, bias=P['enc_b'][i], bn_scale=sc[i * F:(i + 1) * F],
+                                     bn_shift=sh[i * F:(i + 1) * F], relu=True, x_scale=es[i:i + 1], w_scale=es[0:1])
+            elif nsplit > 1:
                 # short layer (T_out down to 104): too few tiles for 256 CUs, but K = 5*768 is long: split-K into the
                 # output buffer (plain STORE + atomics), then relu / save / BatchNorm affine as a second, tiny pass
                 K.conv_gemm(x0=ws['X'][i - 1], w=P['enc_w'][i - 1], bias=P['enc_b'][i], out0=ws['X'][i], B=B, T_in=Tin,
@@ -431,6 +453,16 @@ class VQVAE:
         K.conv_gemm(x0=ws['X'][5], w=P['enc_w6'], bias=P['enc_b6'], out0=ws['z_e'], save0=ws['y6'] if save else None,
                     scale=sc[6 * F:], shift=sh[6 * F:], B=B, T_in=Tz, T_out=Tz, M=D, C0=F, taps=[0])
         self._quantise(spk, ws)
+
+    def _enc_x3_layers(self, ws):
+        """Encoder layers (1..3) whose conv and input gradient run on the fp16x3 engine this step: the guarded engine is active,
+        channel blocks of 128, whole 256-column tiles over the flat (batch, time) rows.  Slots of ws['enc_scale'] / ws['enc_amax']:
+        0 the kernels, i = 1..3 the input of layer i (X[i-1]), 3 + i the gradient of layer i's conv output."""
+        if not (self.x3_guard and self._x3_active and not self.bf16 and self.enc == '64' and self.F % 256 == 0
+                and os.environ.get('VQW_ENC_X3', '1') != '0' and 'ewtp' in ws):      # (training workspaces only: the step's
+            return ()                                                                   #  range flag is read by train_step)
+        B, Tl = ws['B'], ws['Tl']
+        return tuple(i for i in (1, 2, 3) if (B * Tl[i]) % 256 == 0 and Tl[i - 1] == 2 * Tl[i])
 
     def _side_stream(self):
         if self._side is None:
@@ -793,13 +825,15 @@ class VQVAE:
         K.conv_gemm(x0=dz, w=Tt['enc_w6'], out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
-        # the long layers' weight gradients on the fp16x3 engine too (when the decoder's ran there this step): operands split in
-        # registers with exact power-of-two scales of THIS step's tensors (max-abs pass, then 2^13 / amax), bias sums riding along
-        enc_x3 = ('wslab' in ws and bool(ws.get('x3_used')) and self.x3_guard and not self.bf16 and F % 256 == 0
-                  and os.environ.get('VQW_ENC_WGRAD_X3', '1') != '0')
-        if enc_x3 and 'enc_amax' not in ws:
-            ws['enc_amax'] = torch.zeros(2, dtype=torch.int32, device=self.dev)
-            ws['enc_scale'] = torch.ones(2, device=self.dev)
+        # layers 1..3 on the fp16x3 engine: the input gradient where the forward conv ran there (ws['enc_x3']), the weight
+        # gradient (operands split in registers, bias sums riding along) whenever the decoder's ran there this step.  Scales:
+        # exact powers of two from max-abs passes over THIS step's tensors (slots: _enc_x3_layers)
+        ex3 = ws.get('enc_x3', ())
+        wg3 = ('wslab' in ws and bool(ws.get('x3_used')) and self.x3_guard and not self.bf16 and F % 256 == 0
+               and os.environ.get('VQW_ENC_WGRAD_X3', '1') != '0')
+        ea, es, flag = ws.get('enc_amax'), ws.get('enc_scale'), self.x3_flag
+        if ex3:
+            K.f16x3_pack_weights(Tt['enc_w'], ws['ewtp'], 5 * F, F, F, 1.0, count=3, scale_dev=es[0:1], mode=0)
         for i in range(5, -1, -1):
             dX, r = ws['dX'][i], ws['r'][i]
             Ti = ws['Tl'][i]
@@ -808,19 +842,23 @@ class VQVAE:
             K.bn_relu_bwd(dX, r, sc[i * F:(i + 1) * F], dX)          # dX := d(conv_i output)
             Tin = ws['Tl'][i - 1] if i > 0 else T
             pl, _ = same_pads(Tin, 5, 2)
+            on_c = i in ex3
+            on_w = wg3 and 1 <= i <= 3 and Ti % 32 == 0 and Tin == 2 * Ti and B * F * Tin * 4 < (1 << 31)
+            if on_c or on_w:
+                K.f16x3_amax(dX, ea[3 + i:4 + i], flag=flag)
+                K.f16x3_update_scales(ea[3 + i:4 + i], es[3 + i:4 + i], target_exp=13, flag=flag)
+                if not on_c:                                         # (the forward pass measured X[i-1] otherwise)
+                    K.f16x3_amax(ws['X'][i - 1], ea[i:i + 1], flag=flag)
+                    K.f16x3_update_scales(ea[i:i + 1], es[i:i + 1], target_exp=13, flag=flag)
             if side is not main:
                 ready = torch.cuda.Event()
                 ready.record(main)
             with torch.cuda.stream(side):                            # weight / bias gradients: nothing downstream waits
                 if side is not main:
                     side.wait_event(ready)
-                if i > 0 and enc_x3 and Ti % 32 == 0 and B * F * Tin * 4 < (1 << 31):
-                    ea, es = ws['enc_amax'], ws['enc_scale']
-                    K.f16x3_amax(ws['X'][i - 1], ea[0:1])
-                    K.f16x3_amax(dX, ea[1:2])
-                    K.f16x3_update_scales(ea, es, target_exp=13)
+                if on_w:
                     K.f16x3_wgrad(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], slab=ws['wslab'], B=B, T=Ti, Cp=F, Q0=F,
-                                  taps=[j - pl for j in range(5)], p_scale=es[0:1], q0_scale=es[1:2], p_stride=2, T_p=Tin,
+                                  taps=[j - pl for j in range(5)], p_scale=es[i:i + 1], q0_scale=es[3 + i:4 + i], p_stride=2, T_p=Tin,
                                   q_total=G['enc_b'][i], mode=0)
                 else:
                     K.rowsum(dX, total=G['enc_b'][i])
@@ -831,6 +869,11 @@ class VQVAE:
                                      taps=[j - pl for j in range(5)])
             if i == 0:
                 break
+            if on_c:
+                K.f16x3_split_activations(dX, ws['eplanes'], B, F, Ti, scale_dev=es[3 + i:4 + i], mode=0)
+                K.f16x3_strided_conv(xp=ws['eplanes'], wp=ws['ewtp'][i - 1], out=ws['dX'][i - 1], B=B, T=Ti, Cin=F, M=F, ks=5,
+                                     pad_left=pl, dgrad=True, x_scale=es[3 + i:4 + i], w_scale=es[0:1])
+                continue
             # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
             nsplit = self._short_layer_split(F, (Tin + 1) // 2, B)
             if nsplit > 1:
@@ -881,7 +924,7 @@ class VQVAE:
         world = self.grad_sync.finish() if self.grad_sync is not None else 1
         if self.bf16 and ws.get('x3_used'):
             self.x3_steps += 1
-        if self.x3_guard and ws.get('x3_used'):
+        if self.x3_guard and (ws.get('x3_used') or ws.get('enc_x3')):
             if self._x3_overflowed():
                 self.x3_fallbacks += 1
                 self._x3_active = False
