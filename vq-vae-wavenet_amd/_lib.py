@@ -80,7 +80,7 @@ class F16x3SconvDesc(C.Structure):
         ('xp', _fp), ('wp', _fp), ('bias', _fp), ('bn_scale', _fp), ('bn_shift', _fp), ('out', _fp), ('save_r', _fp),
         ('x_scale', _fp), ('w_scale', _fp), ('w_scale_inv', C.c_float),
         ('B', C.c_int32), ('T', C.c_int32), ('Cin', C.c_int32), ('M', C.c_int32), ('ks', C.c_int32), ('pad_left', C.c_int32),
-        ('relu', C.c_int32), ('dgrad', C.c_int32),
+        ('relu', C.c_int32), ('dgrad', C.c_int32), ('shape', C.c_int32),
     ]
 
 

@@ -112,7 +112,19 @@ __global__ void split_act_kernel(const float* __restrict__ x, uint4* __restrict_
             if (!BF) planes[((size_t)KC + kc0 + kc) * NB + row] = p1;
         }
     }
-    guard_report(m, bad, sc, amax, flag);
+    if (!amax && !flag) return;
+    // one atomic per block (see guard_report: same-address atomics of tens of thousands of waves serialise)
+    __shared__ float smax[4];
+    __shared__ int sbad[4];
+    const float wm = wave_max(m);
+    const bool wbad = __any(bad || !(m * sc <= F16_MAX));
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = wm; sbad[threadIdx.x >> 6] = wbad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bits = __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+        if (amax && bits > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bits);
+        if (flag && (sbad[0] | sbad[1] | sbad[2] | sbad[3])) atomicOr(flag, 1);
+    }
 }
 
 // max |x| over `count` strided matrices [rows][cols] (row stride ld, matrix stride mstride) -> amax[blockIdx.y]
@@ -241,6 +253,7 @@ struct OutArgs {
 #define VQW_WG_PAT_A 4     // weight-gradient loop: VALU / LDS instructions per MFMA while a chunk is converted ...
 #define VQW_WG_PAT_B 2      // ... and address computations / requests per MFMA in the second stage
 #endif
+
 #ifndef VQW_X3_PAT_MEM
 #define VQW_X3_PAT_MEM 1      // issue pattern of the conv main loop: LDS / global-memory instructions per MFMA ...
 #define VQW_X3_PAT_ALU 2      // ... and address computations per MFMA (tools/x3_bench.py: 1/2 measured best)
@@ -286,12 +299,12 @@ template <int MR> struct X3Shape {
     static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
     static constexpr int DEPTH = MR == 8 ? 2 : 1;                 // stages of requests in flight
 };
-template <bool BF, int MR, bool TAB = false>
+template <bool BF, int MR, bool TAB = false, int DEPTH = X3Shape<MR>::DEPTH>
 __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem, const LoopGeom& g, int wv, int lane) {
     constexpr int NP = BF ? 1 : 2;        // planes per operand
     constexpr int NA = MR * NP / 4, NBP = 2 * NP;      // weight / activation pieces a wave moves per step
     if (MR == 4) x3_stagger(VQW_X3_STAGGER);
-    constexpr int NSTG_ = X3Shape<MR>::NSTAGE, STGB = X3Shape<MR>::STAGE_BYTES, BOFF = MR * 2 * 1024, DEPTH = X3Shape<MR>::DEPTH;
+    constexpr int NSTG_ = DEPTH + 2, STGB = X3Shape<MR>::STAGE_BYTES, BOFF = MR * 2 * 1024;      // (DEPTH: stages of requests in flight)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int KCA = (TAB ? g.wks : g.ks) * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
     const int nsteps = g.ks * spt;
@@ -665,9 +678,12 @@ struct SconvArgs {
     vqw_f16x3_sconv_desc d;
     int NB;
 };
-__global__ __launch_bounds__(256, 2) void sconv_f16x3_kernel(const SconvArgs a) {
+// Block shapes: MR = 4 / DEPTH 1 (128 rows, two blocks per CU), MR = 4 / DEPTH 2 (one block per CU with two stages of requests
+// in flight: launches of <= CUs blocks, where nothing else hides the operand latency), MR = 8 / DEPTH 2 (256 rows).
+template <int MR, int DEPTH>
+__global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f16x3_kernel(const SconvArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int MR = 4, HB = 32 * MR;
+    constexpr int HB = 32 * MR;
     const vqw_f16x3_sconv_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int T = d.T, M = d.M;
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void sconv_f16x3_kernel(const SconvArgs a) 
     g.m_row0 = mt * HB; g.n0 = n0; g.t0 = 0; g.wks = d.ks;
     if (!d.dgrad) {
         g.ks = d.ks; g.xKC = 2 * d.Cin / 8; g.tj0 = 0; g.tjstep = 1; g.toff = d.pad_left; g.tsgn = -1; g.ts2d = 1;
-        f16x3_mainloop<false, MR, true>(acc, smem, g, wv, lane);
+        f16x3_mainloop<false, MR, true, DEPTH>(acc, smem, g, wv, lane);
         const bool hb = d.bias != nullptr, hs = d.bn_scale != nullptr, sv = d.save_r != nullptr;
         const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);
         const float* sp = hs ? d.bn_scale : reinterpret_cast<const float*>(d.wp);
@@ -717,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void sconv_f16x3_kernel(const SconvArgs a) 
             g.tj0 = (r + d.pad_left) & 1; g.toff = r + d.pad_left;
             g.ks = (d.ks - g.tj0 + 1) / 2;                       // taps of this parity (>= 1 for ks >= 2)
             if (r) __syncthreads();                              // the first run's last stage is still being read
-            f16x3_mainloop<false, MR, true>(acc, smem, g, wv, lane);
+            f16x3_mainloop<false, MR, true, DEPTH>(acc, smem, g, wv, lane);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -1178,10 +1194,20 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     SconvArgs a;
     a.d = d;
     a.NB = d.B * d.T;
-    const int lds = X3Shape<4>::LDS_BYTES;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sconv_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    // block shape (d.shape forces one).  Measured on the benchmark's layers (tools/sconv_bench.py, us, shapes 1 / 2 / 3):
+    //   forward  T=1664: 316 / 318 / 252   T=832: 167 / 148 / 222   T=416: 165 / 142 / 224
+    //   dgrad    T=1664: 350 / 327 / 460   T=832: 245 / 157 / 370   T=416: 244 / 146 / 369
+    // -> 256-row blocks for a forward launch that fills more than half of the chip with them, otherwise the deep 128-row shape
+    const int cus = vqw_device_cus(), nt = a.NB / 256;
+    int shape = d.shape;
+    if (shape == 0) shape = (!d.dgrad && d.M % 256 == 0 && (d.M / 256) * nt * 2 > cus) ? 3 : 2;
+    VQW_CHECK(shape >= 1 && shape <= 3 && (shape != 3 || d.M % 256 == 0), "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2 or 3 (256-row blocks: M %% 256 == 0)");
+    typedef void (*kfn_t)(SconvArgs);
+    const kfn_t kfn = shape == 3 ? sconv_f16x3_kernel<8, 2> : (shape == 2 ? sconv_f16x3_kernel<4, 2> : sconv_f16x3_kernel<4, 1>);
+    const int mr = shape == 3 ? 8 : 4, lds = (shape == 1 ? 3 : 4) * (mr * 2 + 16) * 1024;      // DEPTH + 2 stages
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_strided_conv: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL(sconv_f16x3_kernel, dim3((d.M / 128) * (a.NB / 256)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3((d.M / (32 * mr)) * nt), dim3(256), lds, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_strided_conv");
     return 0;
 }

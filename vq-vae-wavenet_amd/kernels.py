@@ -312,7 +312,7 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
 
 
 def f16x3_strided_conv(*, xp, wp, out, B, T, Cin, M, ks, pad_left, w_scale_inv=1.0, bias=None, bn_scale=None, bn_shift=None,
-                       save_r=None, relu=False, dgrad=False, x_scale=None, w_scale=None):
+                       save_r=None, relu=False, dgrad=False, x_scale=None, w_scale=None, shape=0):
     """vqw_f16x3_strided_conv: a stride-2 conv (SAME padding, pad_left zeros in front) -> bias -> relu -> BatchNorm affine over
     space-to-depth planes of x [B][Cin][2T] (out [B][M][T]), or with dgrad its input gradient from the planes of dy [B][Cin][T]
     (out [B][M][2T]; wp = planes of the transposed kernel)."""
@@ -332,6 +332,7 @@ def f16x3_strided_conv(*, xp, wp, out, B, T, Cin, M, ks, pad_left, w_scale_inv=1
     d.save_r = None if save_r is None else save_r.data_ptr()
     d.x_scale, d.w_scale, d.w_scale_inv = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale'), float(w_scale_inv)
     d.B, d.T, d.Cin, d.M, d.ks, d.pad_left, d.relu, d.dgrad = B, T, Cin, M, ks, pad_left, int(bool(relu)), int(bool(dgrad))
+    d.shape = shape
     L.check(L.lib().vqw_f16x3_strided_conv(C.byref(d), L.stream()))
 
 
