@@ -408,17 +408,16 @@ typedef struct vqw_f16x3_out_desc {
     uint32_t* out_amax;    /* atomicMax of the bit pattern of max |net_out| (or NULL)                                */
     int32_t* flag;         /* |= 1 when plane_scale * out_scale * |net_out| > 65504 or net_out is not finite (or NULL) */
     int32_t mode;          /* VQW_X3_* bits                                                                          */
+    /* epi 2 -- the 1x1 convs around the stack (wavenet.py:53-54, 80-96) and their input gradients; S = 0, R rows, fp16x3 mode:
+     *   net_out = mask * (net_in + W x + bias + cond[b][m][t / (T / cond_T)]),  mask = (aux0 > 0) or 1 (aux0 NULL); net_in, bias,
+     *   cond optional; net_out may alias net_in and aux0; net_out_planes get net_out, or relu(net_out) with flags bit 0        */
+    const float* cond;
+    int64_t cond_bstride;
+    int32_t cond_T;
+    int32_t flags;
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 
-/* Weight gradient of conv1d_v2 (TF Conv2DBackpropFilter, wavenet_ops.py:83-86) on the fp16x3 engine:
- *   dw[j][c][o] += sum_{b,t} p[b][c][t + tap_shift[j]] * q[b][o][t],   q = [q0 (Q0 rows); q1 (Q1 rows)] along o,
- * p [B][Cp][T], q0 [B][Q0][T], q1 [B][Q1][T] fp32 (time contiguous = the contraction index: the operands are split into
- * fp16 planes inside the kernel, with the power-of-two guard scales *_scale (device scalars or NULL) of the same tensors'
- * planes, whose producers range-check them).  T % 32 == 0; Cp, Q0, Q1 multiples of 256; tap_shift <= 0 (reads outside
- * [0, T) are zero).  `slab` is scratch: tiles * nsplit * 65536 floats (tiles = ntaps * Cp/256 * (Q0+Q1)/256; nsplit 0 =
- * CUs / tiles): partial tiles are summed in a fixed order by a second launch -- dw is bitwise reproducible (q_total /
- * q_seg are met by fp32 atomics).                                                                                  */
 /* The encoder's stride-2 convs on the fp16x3 engine (encoder.py:17-18: tf.layers.conv1d(768, 5, strides 2, 'same') -> relu ->
  * batch_normalization in inference mode, and TF's Conv2DBackpropInput of it).  Kernel w[ks][Cin][M] as planes
  * (vqw_f16x3_pack_weights, K = ks * Cin); for the input gradient the transposed kernel wt[ks][Cout][Cin] with Cin := Cout, M := Cin.
@@ -443,6 +442,14 @@ typedef struct vqw_f16x3_sconv_desc {
 } vqw_f16x3_sconv_desc;
 int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* d, vqw_stream_t s);
 
+/* Weight gradient of conv1d_v2 (TF Conv2DBackpropFilter, wavenet_ops.py:83-86) on the fp16x3 engine:
+ *   dw[j][c][o] += sum_{b,t} p[b][c][t + tap_shift[j]] * q[b][o][t],   q = [q0 (Q0 rows); q1 (Q1 rows)] along o,
+ * p [B][Cp][T], q0 [B][Q0][T], q1 [B][Q1][T] fp32 (time contiguous = the contraction index: the operands are split into
+ * fp16 planes inside the kernel, with the power-of-two guard scales *_scale (device scalars or NULL) of the same tensors'
+ * planes, whose producers range-check them).  T % 32 == 0; Cp, Q0, Q1 multiples of 256; tap_shift <= 0 (reads outside
+ * [0, T) are zero).  `slab` is scratch: tiles * nsplit * 65536 floats (tiles = ntaps * Cp/256 * (Q0+Q1)/256; nsplit 0 =
+ * CUs / tiles): partial tiles are summed in a fixed order by a second launch -- dw is bitwise reproducible (q_total /
+ * q_seg are met by fp32 atomics).                                                                                  */
 typedef struct vqw_f16x3_wgrad_desc {
     const float* p;
     const float* q0;
@@ -466,6 +473,7 @@ typedef struct vqw_f16x3_wgrad_desc {
     int32_t seg_T;
     int32_t total_o0, total_o1;   /* 0, 0 = all of [0, Q0 + Q1)                                              */
     int32_t mode;           /* VQW_X3_* bits                                                                 */
+    int32_t p_relu;         /* p := max(p, 0) on the way in                                                   */
     int32_t p_stride;       /* 0 / 1, or 2: p is the input of a stride-2 conv (encoder.py:17-18), row length Tp, read at
                              * 2 t + tap_shift[j] (shifts of either sign; outside [0, Tp) = zero padding); fp16x3 mode only */
     int32_t Tp;

@@ -666,6 +666,62 @@ def test_strided_conv_f16x3_forward_and_input_gradient(K, B, Tout, Cin, M):
     assert (dx.double() - want_dx.double()).abs().max().item() <= tol * want_dx.abs().max().item()
 
 
+@pytest.mark.parametrize('half', [0, 1])
+def test_head_conv_f16x3_epilogue_options(K, half):
+    """vqw_f16x3_out_conv epi 2 (the 1x1 convs around the stack and their input gradients): mask * (net_in + W x + bias + upsampled
+    condition) in place over the mask source, relu'd planes with their max-abs report -- against fp64."""
+    B, T, Cin, M, Tz = 2, 512, 512, 256, 8
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, T, generator=gen).to(DEV)
+    w = (torch.randn(Cin, M, generator=gen) * 0.05).to(DEV)
+    bias = torch.randn(M, generator=gen).to(DEV)
+    cond = torch.randn(B, M + 3, Tz, generator=gen).to(DEV)            # batch stride wider than the rows read
+    ni = torch.randn(B, M, T, generator=gen).to(DEV)
+    mask_src = torch.randn(B, M, T, generator=gen).to(DEV)
+    sc = torch.tensor([4.0, 64.0, 16.0], device=DEV)
+    md = K.X3_HALF_BLOCKS if half else 0
+    xp = torch.empty(2 * B * Cin * T, dtype=torch.float16, device=DEV)
+    wp = torch.empty(2 * Cin * M, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(x, xp, B, Cin, T, scale_dev=sc[0:1], mode=md)
+    K.f16x3_pack_weights(w, wp, Cin, M, M, 1.0, scale_dev=sc[1:2], mode=md)
+    lin = torch.einsum('cm,bct->bmt', w.double(), x.double()) + bias.double()[None, :, None]
+    up = cond[:, :M].double().repeat_interleave(T // Tz, dim=2)
+    want = (mask_src > 0).double() * (ni.double() + lin + up)
+    out = mask_src.clone()                                             # in place over the mask source
+    planes = torch.zeros(2 * B * M * T, dtype=torch.float16, device=DEV)
+    amax, flag = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    K.f16x3_out_conv(epi=2, xp=xp, Cin=Cin, wp=wp, bias=bias, net_in=ni, net_out=out, aux0=out, cond=cond, cond_T=Tz,
+                     cond_bstride=(M + 3) * Tz, net_out_planes=planes, relu_planes=True, B=B, T=T, R=M, S=0, w_scale_inv=1.0,
+                     x_scale=sc[0:1], w_scale=sc[1:2], out_scale=sc[2:3], out_amax=amax, flag=flag, mode=md)
+    assert (out.double() - want).abs().max().item() <= 3e-6 * want.abs().max().item()
+    pl = planes.view(2, M // 8, B * T, 8).double().sum(0) / 16.0       # [chunk][row][8] -> [B][M][T]
+    got_p = pl.permute(1, 0, 2).reshape(B, T, M).permute(0, 2, 1)
+    assert (got_p - torch.relu(want)).abs().max().item() <= 3e-6 * want.abs().max().item()
+    assert abs(amax.view(torch.float32).item() - torch.relu(want).max().item()) <= 1e-5 * want.abs().max().item()
+    assert flag.item() == 0
+    # plain form: no mask, no net_in, no condition, planes without relu
+    out2 = torch.empty(B, M, T, device=DEV)
+    K.f16x3_out_conv(epi=2, xp=xp, Cin=Cin, wp=wp, bias=bias, net_out=out2, net_out_planes=planes, B=B, T=T, R=M, S=0,
+                     w_scale_inv=1.0, x_scale=sc[0:1], w_scale=sc[1:2], out_scale=sc[2:3], mode=md)
+    assert (out2.double() - lin).abs().max().item() <= 3e-6 * lin.abs().max().item()
+    pl = planes.view(2, M // 8, B * T, 8).double().sum(0) / 16.0
+    assert (pl.permute(1, 0, 2).reshape(B, T, M).permute(0, 2, 1) - lin).abs().max().item() <= 3e-6 * lin.abs().max().item()
+
+
+def test_wgrad_f16x3_relu_operand(K):
+    """p_relu: the weight gradient of a conv that sits behind a relu (wavenet.py:79, 93) reads max(p, 0)."""
+    B, T, Cp, Q0 = 2, 512, 512, 256
+    gen = torch.Generator().manual_seed(43)
+    p = torch.randn(B, Cp, T, generator=gen).to(DEV)
+    q = (torch.randn(B, Q0, T, generator=gen) * 1e-5).to(DEV)
+    sc = torch.tensor([8.0, 2.0 ** 26], device=DEV)
+    dw = torch.zeros(Cp, Q0, device=DEV)
+    slab = torch.empty(256 * 65536, device=DEV)
+    K.f16x3_wgrad(p=p, q0=q, dw=dw, slab=slab, B=B, T=T, Cp=Cp, Q0=Q0, taps=[0], p_scale=sc[0:1], q0_scale=sc[1:2], p_relu=True)
+    want = torch.einsum('bct,bot->co', torch.relu(p).double(), q.double())
+    assert (dw.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
 def test_wgrad_f16x3_full_size_matches_fp32_engine(K):
     """The benchmark's shapes (B=8, T=6656: 1664 stage pairs over 42 / 85 K splits): gate-conv and 1x1 weight gradients
     against the fp32 engine's wgrad kernel and fp64 samples."""

@@ -73,7 +73,9 @@ class F16x3OutDesc(C.Structure):
         ('planes_kc0', C.c_int32), ('planes_KC', C.c_int32), ('plane_scale', C.c_float), ('epi', C.c_int32),
         ('aux0', _fp), ('aux1', _fp),
         ('x_scale', _fp), ('w_scale', _fp), ('out_scale', _fp), ('out_amax', _fp), ('flag', _fp), ('mode', C.c_int32),
+        ('cond', _fp), ('cond_bstride', C.c_int64), ('cond_T', C.c_int32), ('flags', C.c_int32),
     ]
+
 
 class F16x3SconvDesc(C.Structure):
     _fields_ = [
@@ -91,7 +93,7 @@ class F16x3WgradDesc(C.Structure):
         ('B', C.c_int32), ('T', C.c_int32), ('Cp', C.c_int32), ('Q0', C.c_int32), ('Q1', C.c_int32), ('ntaps', C.c_int32),
         ('tap_shift', C.c_int32 * MAX_TAPS), ('lddw', C.c_int32), ('nsplit', C.c_int32), ('dw_tap_stride', C.c_int64),
         ('q_total', _fp), ('q_seg', _fp), ('seg_bstride', C.c_int64), ('seg_T', C.c_int32), ('total_o0', C.c_int32),
-        ('total_o1', C.c_int32), ('mode', C.c_int32), ('p_stride', C.c_int32), ('Tp', C.c_int32),
+        ('total_o1', C.c_int32), ('mode', C.c_int32), ('p_relu', C.c_int32), ('p_stride', C.c_int32), ('Tp', C.c_int32),
     ]
 
 

@@ -599,6 +599,88 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void out_f16x3_kernel(const O
     if (!is_skip && d.net_out_planes) guard_report(gmax, gbad, ps, d.out_amax, d.flag);
 }
 
+// The 1x1 convs around the residual stack (wavenet.py:53-54, 72, 80-96) and their input gradients, epi = 2:
+//   out[b][m][t] = mask * (net_in[b][m][t] + (W x)[m] + bias[m] + cond[b][m][t / ratio]),   mask = (aux0[b][m][t] > 0) or 1
+// (net_in, bias, cond, aux0 optional; out may be net_in and / or aux0: every element is read and written by one lane), and
+// out -- or relu(out), flags bit 0 -- once more as planes for the next contraction, range-checked like the others.
+template <int MR>
+__global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void head_f16x3_kernel(const OutArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const vqw_f16x3_out_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int M = d.R, T = d.T;
+    constexpr int HB = 32 * MR;
+    const int n_mt = M / HB;
+    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
+    const int b = n0 / T, t0 = n0 - b * T;
+    f32x16 acc[MR][2];
+    {
+        LoopGeom g;
+        g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = d.Cin; g.ks = 1; g.dilation = 1; g.NB = a.NB;
+        g.xKC = d.xp_KC > 0 ? d.xp_KC : d.Cin / 8; g.xkc0 = d.xp_kc0; g.dir = 1; g.T = T;
+        g.m_row0 = mt * HB; g.n0 = n0; g.t0 = t0;
+        f16x3_mainloop<false, MR>(acc, smem, g, wv, lane);
+    }
+    const bool hb = d.bias != nullptr, hc = d.cond != nullptr, hin = d.net_in != nullptr, hm = d.aux0 != nullptr;
+    const bool relu_planes = (d.flags & 1) != 0;
+    const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);      // absent operands read a valid dummy address
+    const float* cb = hc ? d.cond + (size_t)b * d.cond_bstride : reinterpret_cast<const float*>(d.wp);
+    const int ratio = hc ? T / d.cond_T : 1;
+    const int tz[2] = {(t0 + 64 * wv) / ratio, (t0 + 64 * wv + 32) / ratio};   // 32 | ratio: one frame per tile row
+    const int tcol = t0 + 64 * wv + l31;
+    const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
+    const float ps = (d.plane_scale > 0.0f ? d.plane_scale : 1.0f) * dev_scale(d.out_scale);
+    const int PKC = d.planes_KC > 0 ? d.planes_KC : M / 8;
+    float gmax = 0.0f;
+    bool gbad = false;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            const int m0 = mt * HB + 32 * i + 8 * v4 + 4 * lhi;      // first of this lane's four rows
+            const size_t off = ((size_t)b * M + m0) * T + tcol;
+            const float* pin = hin ? d.net_in + off : d.net_out + off;
+            const float* pm = hm ? d.aux0 + off : d.net_out + off;
+            float* pout = d.net_out + off;
+            float add[4][2], old[2][4], mk[2][4], nq[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bv = bp[hb ? m0 + e : 0];
+                const int cr = (m0 + e) * d.cond_T;
+                const float c0 = cb[hc ? cr + tz[0] : 0], c1 = cb[hc ? cr + tz[1] : 0];
+                add[e][0] = (hb ? bv : 0.0f) + (hc ? c0 : 0.0f);
+                add[e][1] = (hb ? bv : 0.0f) + (hc ? c1 : 0.0f);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float ov = pin[e * T + 32 * j], mv = pm[e * T + 32 * j];
+                    old[j][e] = hin ? ov : 0.0f;
+                    mk[j][e] = (!hm || mv > 0.0f) ? 1.0f : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    nq[j][e] = mk[j][e] * (old[j][e] + (acc[i][j][v4 * 4 + e] * winv + add[e][j]));
+                    pout[e * T + 32 * j] = nq[j][e];
+                }
+            if (d.net_out_planes) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gbad |= !(fabsf(nq[j][e]) <= 3.0e38f);
+                        if (relu_planes) nq[j][e] = fmaxf(nq[j][e], 0.0f);
+                        gmax = fmaxf(gmax, fabsf(nq[j][e]));
+                    }
+                    store_plane_quad<false>(d.net_out_planes, PKC, a.NB, d.planes_kc0 + m0 / 8, n0 + 64 * wv + 32 * j + l31, lhi, nq[j], ps);
+                }
+            }
+        }
+    if (d.net_out_planes) guard_report(gmax, gbad, ps, d.out_amax, d.flag);
+}
+
 // Gate backward (the transpose of gated_cnn's tanh * sigmoid, wavenet_ops.py:112-113, behind the transposed 1x1 convs):
 // dg = W_out^T [dskip; dnet] over the gradient planes (dskip in chunks 0..S/8-1, dnet behind it), then
 // dpre[filter c] = dg * sg * (1 - th^2), dpre[gate c] = dg * th * sg * (1 - sg); dpre also as planes for the input gradient.
@@ -772,6 +854,7 @@ struct WgArgs {
     const float* sq1;
     int B, T, Cp, Q0, Q1, ntaps;
     int Tp;               // row length of p (= T, or the input length of a stride-2 conv: p index 2 t + shift)
+    int p_relu;           // p := max(p, 0) on the way in (the convs behind a relu, wavenet.py:79, 93)
     int shift[VQW_MAX_TAPS];
     int nsplit, pairs_row, pairs_total, n_nt;
     // sums of q over time, formed from the registers that hold q anyway (blocks of the first row tile only):
@@ -815,6 +898,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const float* qsrc = from_q1 ? a.q1 : a.q0;
     const int Qs = from_q1 ? a.Q1 : a.Q0, oq = from_q1 ? o0 - a.Q0 : o0;
     const float scp = dev_scale(a.sp), scq = dev_scale(from_q1 ? a.sq1 : a.sq0);
+    const float plo = a.p_relu ? 0.0f : -INFINITY;
     const int T = a.T;
     const int s_begin = (int)((long)split * a.pairs_total / a.nsplit), s_end = (int)((long)(split + 1) * a.pairs_total / a.nsplit);
     const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(a.p, (unsigned)((size_t)a.B * a.Cp * (S2 ? a.Tp : T) * 4));
@@ -864,7 +948,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         const int g = wv * 2 + (n >> 2), nn = n & 3;
         char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STG_BYTES + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
         uint2 lo;
-        uint2 hi = split4<BF>(rgp[n], scp, lo);
+        f32x4 pv = rgp[n];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[e] = fmaxf(pv[e], plo);
+        uint2 hi = split4<BF>(pv, scp, lo);
         *reinterpret_cast<uint2*>(st + (g * 2 + 0) * 1024) = hi;
         if (!BF) *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
         hi = split4<BF>(rgq[n], scq, lo);
@@ -1132,6 +1219,17 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     const kfn_t kbwds[4] = {gate_bwd_f16x3_kernel<false, 8>, gate_bwd_f16x3_kernel<true, 8>, gate_bwd_f16x3_kernel<false, 4>, gate_bwd_f16x3_kernel<true, 4>};
     const int lds = half ? X3Shape<4>::LDS_BYTES : X3Shape<8>::LDS_BYTES, hb = half ? 128 : 256;
     const bool bwd = d.epi == 1;
+    if (d.epi == 2) {
+        VQW_CHECK(d.S == 0 && d.R > 0 && d.net_out && d.Cin > 0 && !bf && d.ks <= 1, "vqw_f16x3_out_conv: epi 2 needs S = 0, net_out, Cin, a 1x1 kernel and the fp16x3 mode");
+        VQW_CHECK(!d.cond || (d.cond_T > 0 && d.T % d.cond_T == 0 && (d.T / d.cond_T) % 32 == 0 && d.cond_bstride >= (int64_t)d.R * d.cond_T),
+                  "vqw_f16x3_out_conv: T / cond_T must be a multiple of 32 (T=%d cond_T=%d)", d.T, d.cond_T);
+        const kfn_t kfn = half ? head_f16x3_kernel<4> : head_f16x3_kernel<8>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", lds);
+        hipLaunchKernelGGL(kfn, dim3((d.R / hb) * (a.NB / 256)), dim3(256), lds, st, a);
+        VQW_LAUNCH_CHECK("vqw_f16x3_out_conv");
+        return 0;
+    }
     if (bwd) VQW_CHECK(d.S == 0 && d.R > 0 && d.aux0 && d.aux1 && d.Cin > 0, "vqw_f16x3_out_conv: gate backward needs S = 0, saved tanh (aux0) and sigmoid (aux1), Cin");
     const kfn_t kfn = (bwd ? kbwds : kouts)[(bf ? 1 : 0) + (half ? 2 : 0)];
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -1235,7 +1333,7 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     WgArgs a;
     memset(&a, 0, sizeof(a));
     a.p = d.p; a.q0 = d.q0; a.q1 = d.q1; a.slab = d.slab; a.sp = d.p_scale; a.sq0 = d.q0_scale; a.sq1 = d.q1_scale;
-    a.B = d.B; a.T = d.T; a.Cp = d.Cp; a.Q0 = d.Q0; a.Q1 = d.Q1; a.ntaps = d.ntaps; a.Tp = Tp;
+    a.B = d.B; a.T = d.T; a.Cp = d.Cp; a.Q0 = d.Q0; a.Q1 = d.Q1; a.ntaps = d.ntaps; a.Tp = Tp; a.p_relu = d.p_relu;
     for (int j = 0; j < d.ntaps; ++j) a.shift[j] = d.tap_shift[j];
     a.pairs_row = d.T / 32; a.pairs_total = d.B * a.pairs_row;
     a.n_nt = (d.Q0 + d.Q1) / 256;

@@ -272,7 +272,9 @@ def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mo
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
                    net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
                    planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None, x_scale=None, w_scale=None,
-                   out_scale=None, out_amax=None, flag=None, mode=None):
+                   out_scale=None, out_amax=None, flag=None, mode=None, cond=None, cond_T=0, cond_bstride=0, relu_planes=False):
+    """vqw_f16x3_out_conv; epi 0: skip rows += / residual rows = net_in + W x + b; epi 1: gate backward; epi 2: the 1x1 convs
+    around the stack: net_out = (aux0 > 0) * (net_in + W x + bias + cond), planes of net_out or relu(net_out)."""
     mode = x3_mode(mode)
     cin = Cin if Cin > 0 else R
     kc_all = xp_KC if xp_KC > 0 else cin // 8
@@ -287,6 +289,8 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     if epi == 1:
         _need(aux0, B * R * T, 'aux0')
         _need(aux1, B * R * T, 'aux1')
+    if epi == 2 and aux0 is not None:
+        _need(aux0, B * R * T, 'aux0')
     if bias is not None:
         _need(bias, S + R, 'bias')
     if net_out_planes is not None:
@@ -308,6 +312,10 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     d.x_scale, d.w_scale, d.out_scale = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale'), _slot(out_scale, 'out_scale')
     d.out_amax, d.flag = _slot(out_amax, 'out_amax', torch.int32), _slot(flag, 'flag', torch.int32)
     d.mode = mode
+    if cond is not None:
+        _need(cond, (B - 1) * cond_bstride + R * cond_T, 'cond')
+        d.cond, d.cond_T, d.cond_bstride = cond.data_ptr(), cond_T, cond_bstride
+    d.flags = 1 if relu_planes else 0
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 
 
@@ -373,7 +381,7 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
 
 def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
                 q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=None,
-                p_stride=1, T_p=None):
+                p_stride=1, T_p=None, p_relu=False):
     """vqw_f16x3_wgrad: dw[j][c][o] += sum_{b,t} p[b][c][p_stride*t+taps[j]] * q[b][o][t] on the fp16x3 engine (slab = scratch;
     p_stride 2: p rows are T_p long, indices outside [0, T_p) are zero padding)."""
     mode = x3_mode(mode)
@@ -387,7 +395,7 @@ def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None
     _need(dw, (len(taps) - 1) * dw_tap_stride + (Cp - 1) * lddw + Q0 + Q1, 'dw')
     _need(slab, 65536, 'slab')
     d = L.F16x3WgradDesc()
-    d.p_stride, d.Tp = p_stride, T_p
+    d.p_stride, d.Tp, d.p_relu = p_stride, T_p, int(bool(p_relu))
     d.p, d.q0, d.q1, d.dw, d.slab = p.data_ptr(), q0.data_ptr(), (None if q1 is None else q1.data_ptr()), dw.data_ptr(), slab.data_ptr()
     d.slab_floats = slab.numel()
     d.p_scale, d.q0_scale, d.q1_scale = _slot(p_scale, 'p_scale'), _slot(q0_scale, 'q0_scale'), _slot(q1_scale, 'q1_scale')
