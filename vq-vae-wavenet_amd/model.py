@@ -136,10 +136,14 @@ class VQVAE:
         #   WG all gate kernels | WO all 1x1 skip/residual kernels | G = dskip and every dnet (they share one contraction)
         #   X[l] input planes of layer l (l = 0..L) | DP[l] d pre-activation of layer l
         L = self.L
-        self.SL = {'WG': 0, 'WO': 1, 'G': 2, 'X': 3, 'DP': 3 + L + 1, 'N': 3 + 2 * L + 1}
+        #   SK relu(skip) planes | H1 relu(postprocess1) planes | DH d postprocess1 | WH the three kernels around the stack
+        n = 3 + 2 * L + 1
+        self.SL = {'WG': 0, 'WO': 1, 'G': 2, 'X': 3, 'DP': 3 + L + 1, 'SK': n, 'H1': n + 1, 'DH': n + 2, 'WH': n + 3, 'N': n + 4}
         self.x3_scale = torch.ones(self.SL['N'], device=self.dev)
         self.x3_scale[self.SL['G']] = 2.0 ** 20          # first step: |d loss / d logits| <= 1 / (B T)
-        self.x3_scale[self.SL['DP']:] = 2.0 ** 20
+        self.x3_scale[self.SL['DP']:self.SL['SK']] = 2.0 ** 20
+        self.x3_scale[self.SL['DH']] = 2.0 ** 20
+        self.head_x3 = os.environ.get('VQW_HEAD_X3', '1') != '0'
         self.x3_amax = torch.zeros(self.SL['N'], dtype=torch.int32, device=self.dev)
         self.x3_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
@@ -380,6 +384,14 @@ class VQVAE:
             if self.skip_f16x3:
                 ws['wskip'] = torch.empty(2 * L * R * S, dtype=torch.float16, device=dev)
                 ws['wres'] = torch.empty(L, 2 * R * R, dtype=torch.float16, device=dev)
+                if self.x3_guard and self.gbwd_f16x3 and S % 256 == 0 and Q % 256 == 0:     # the convs around the stack on the engine too
+                    ws['hp'] = torch.empty(2 * B * S * T, dtype=torch.float16, device=dev)     # relu(skip) / d postprocess1 planes
+                    ws['hp2'] = torch.empty(2 * B * S * T, dtype=torch.float16, device=dev)    # relu(postprocess1) / d logits planes
+                    for name, n_ in (('wskip0', R * S), ('wpost1', S * S), ('wpost2', S * Q)):
+                        ws[name] = torch.empty(2 * n_, dtype=torch.float16, device=dev)
+                        ws[name + 't'] = torch.empty(2 * n_, dtype=torch.float16, device=dev)
+                    # |d loss / d logits| <= 1 / (B T): a fixed power-of-two scale, max-abs below 2^13
+                    ws['dl_scale'] = torch.full((1,), 2.0 ** math.floor(math.log2(2.0 ** 13 * B * T)), device=dev)
             ws['wop_all'] = torch.empty(L, 2 * R * (S + R), dtype=torch.float16, device=dev)
             ws['wop'] = [ws['wop_all'][l] for l in range(L)]
         ws['h1'] = e(B, S, T)
@@ -499,8 +511,6 @@ class VQVAE:
         net = ws['net']
         K.conv_cin1_fwd(ws['inputs'], P['pre_w'], P['pre_b'], net[0], k=self.pre_k, stride=1,
                         offset=-(self.pre_k - 1))                                         # wavenet.py:42-44
-        K.conv_gemm(x0=net[0], w=P['skip0_w'], bias=P['skip0_b'], out0=ws['skip'], B=B, T_in=T, T_out=T, M=S,
-                    C0=R, taps=[0])                                                       # wavenet.py:53-54
         cbs = self.Mall * Tz
         ce_flat = ws['condenc'].view(-1)   # layer l's rows start at l*2R*Tz inside every batch block
         # fp16x3 needs whole 256-step tiles inside a batch row, 128-channel blocks and one condition frame per 32 steps;
@@ -517,6 +527,7 @@ class VQVAE:
         am = (lambda name, i=0: self.x3_amax[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
         flag = self.x3_flag if gd else None
         WS = 1.0 if gd else 256.0          # guarded: the weight scale lives on the device (exact max-abs of this step's weights)
+        head_x3 = ws['head_x3'] = bool(gd and self.head_x3 and 'hp' in ws and T % 32 == 0)
         if gd:
             K.f16x3_amax(P['gated_w'], am('WG'), flag=flag)
             K.f16x3_amax(P['out_w'], am('WO'), flag=flag)
@@ -524,6 +535,20 @@ class VQVAE:
             # weights and the first layer's input: exact scales (amax < 2^14 after scaling); the collectors restart
             K.f16x3_update_scales(self.x3_amax[:2], self.x3_scale[:2], target_exp=14, flag=flag)
             K.f16x3_update_scales(am('X', 0), sc('X', 0), target_exp=13, flag=flag)
+        if head_x3:      # the three kernels around the stack share one scale
+            for name in ('skip0_w', 'post1_w', 'post2_w'):
+                K.f16x3_amax(P[name], am('WH'), flag=flag)
+            K.f16x3_update_scales(am('WH'), sc('WH'), target_exp=14, flag=flag)
+            K.f16x3_pack_weights(P['skip0_w'], ws['wskip0'], R, S, S, 1.0, scale_dev=sc('WH'), mode=md)
+            K.f16x3_pack_weights(P['post1_w'], ws['wpost1'], S, S, S, 1.0, scale_dev=sc('WH'), mode=md)
+            K.f16x3_pack_weights(P['post2_w'], ws['wpost2'], S, Q, Q, 1.0, scale_dev=sc('WH'), mode=md)
+            # wavenet.py:53-54 on the first layer's input planes
+            K.f16x3_split_activations(net[0], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
+            K.f16x3_out_conv(xp=ws['xp'], Cin=R, wp=ws['wskip0'], bias=P['skip0_b'], net_out=ws['skip'], B=B, T=T, R=S, S=0,
+                             w_scale_inv=1.0, x_scale=sc('X', 0), w_scale=sc('WH'), mode=md)
+        else:
+            K.conv_gemm(x0=net[0], w=P['skip0_w'], bias=P['skip0_b'], out0=ws['skip'], B=B, T_in=T, T_out=T, M=S,
+                        C0=R, taps=[0])                                                   # wavenet.py:53-54
         if f16x3:      # this step's weights of all layers as fp16 planes, one launch per kind
             K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, WS, count=L, scale_dev=sc('WG'), mode=md)
             if f16x3_skip:     # [L*R][S] skip kernels of all layers as one K = L*R operand; the residual kernels per layer
@@ -533,7 +558,7 @@ class VQVAE:
                 K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, WS, count=L, mode=md)
         for l, d in enumerate(self.dil):
             if f16x3:
-                if l == 0 or not f16x3_out:
+                if (l == 0 and not head_x3) or not f16x3_out:
                     K.f16x3_split_activations(net[l], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
                 K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if save else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
@@ -562,6 +587,18 @@ class VQVAE:
             K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
                         aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
                         epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])                                       # :132-136, wavenet.py:72-73
+        if head_x3:      # the same contraction hands relu(skip) over as planes; wavenet.py:80-96 on planes
+            K.f16x3_out_conv(epi=2, xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
+                             net_in=ws['skip'], net_out=ws['skip'], net_out_planes=ws['hp'], relu_planes=True, B=B, T=T, R=S, S=0,
+                             w_scale_inv=1.0 / WS, w_scale=sc('WO'), out_scale=sc('SK'), out_amax=am('SK'), flag=flag,
+                             mode=self.x3_mode_skip)
+            K.f16x3_out_conv(epi=2, xp=ws['hp'], Cin=S, wp=ws['wpost1'], bias=P['post1_b'], cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz,
+                             cond_bstride=cbs, net_out=ws['h1'], net_out_planes=ws['hp2'], relu_planes=True, B=B, T=T, R=S, S=0,
+                             w_scale_inv=1.0, x_scale=sc('SK'), w_scale=sc('WH'), out_scale=sc('H1'), out_amax=am('H1'), flag=flag,
+                             mode=md)
+            K.f16x3_out_conv(epi=2, xp=ws['hp2'], Cin=S, wp=ws['wpost2'], bias=P['post2_b'], net_out=ws['logits'], B=B, T=T, R=Q,
+                             S=0, w_scale_inv=1.0, x_scale=sc('H1'), w_scale=sc('WH'), mode=md)
+            return
         if f16x3_skip:   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
             K.f16x3_out_conv(xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
                              skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / WS, w_scale=sc('WO'), mode=self.x3_mode_skip)
@@ -656,18 +693,49 @@ class VQVAE:
         dlog, h1, skip = ws['logits'], ws['h1'], ws['skip']
         cbs = self.Mall * Tz
         dce = ws['dcondenc']
-        # ---- postprocess2 (wavenet.py:93-96)
-        K.wgrad_gemm(p=h1, p_relu=True, q0=dlog, dw=G['post2_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=Q, taps=[0])
-        K.rowsum(dlog, total=G['post2_b'])
-        K.conv_gemm(x0=dlog, w=Tt['post2_w'], out0=h1, aux0=h1, B=B, T_in=T, T_out=T, M=S, C0=Q, taps=[0],
-                    epilogue=K.EPI_MASK)                       # h1 := d h1 (pre-relu)
-        # ---- postprocess1 (wavenet.py:79-88)
-        K.wgrad_gemm(p=skip, p_relu=True, q0=h1, dw=G['post1_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=S, taps=[0])
-        seg_p1 = torch.empty(B, S, Tz, device=self.dev)
-        K.rowsum(h1, seg_out=seg_p1, total=G['post1_b'], seg=ratio)
-        dce[:, L * 2 * R:].copy_(seg_p1)
-        K.conv_gemm(x0=h1, w=Tt['post1_w'], out0=skip, aux0=skip, B=B, T_in=T, T_out=T, M=S, C0=S, taps=[0],
-                    epilogue=K.EPI_MASK)                       # skip := d skip (same for every layer)
+        head_x3 = bool(ws.get('head_x3')) and bool(ws.get('x3_used')) and self.x3_guard
+        if head_x3:
+            # the convs around the stack on the fp16x3 engine (forward: _decode_train): d logits as planes with a fixed scale
+            # (|d logits| <= 1 / (B T)), each input gradient hands the next one its planes, the weight gradients split their fp32
+            # operands in registers (p = relu of the forward tensor), bias and condition sums ride along
+            hsc = lambda name: self.x3_scale[self.SL[name]:self.SL[name] + 1]      # noqa: E731
+            ham = lambda name: self.x3_amax[self.SL[name]:self.SL[name] + 1]       # noqa: E731
+            mdh, dl, hflag = self.x3_mode_bwd, ws['dl_scale'], self.x3_flag
+            if 'wslab' not in ws:
+                ws['wslab'] = torch.empty(256 * 65536, device=self.dev)
+            K.f16x3_pack_weights(Tt['post2_w'], ws['wpost2t'], Q, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
+            K.f16x3_pack_weights(Tt['post1_w'], ws['wpost1t'], S, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
+            K.f16x3_pack_weights(Tt['skip0_w'], ws['wskip0t'], S, R, R, 1.0, scale_dev=hsc('WH'), mode=mdh)
+            dce.zero_()
+            # ---- postprocess2 (wavenet.py:93-96)
+            K.f16x3_split_activations(dlog, ws['hp2'], B, Q, T, scale_dev=dl, mode=mdh)
+            K.f16x3_wgrad(p=h1, p_relu=True, q0=dlog, dw=G['post2_w'], slab=ws['wslab'], B=B, T=T, Cp=S, Q0=Q, taps=[0],
+                          p_scale=hsc('H1'), q0_scale=dl, q_total=G['post2_b'], mode=mdh)
+            K.f16x3_out_conv(epi=2, xp=ws['hp2'], Cin=Q, wp=ws['wpost2t'], net_out=h1, aux0=h1, net_out_planes=ws['hp'], B=B, T=T,
+                             R=S, S=0, w_scale_inv=1.0, x_scale=dl, w_scale=hsc('WH'), out_scale=hsc('DH'), out_amax=ham('DH'),
+                             flag=hflag, mode=mdh)                 # h1 := d h1 (pre-relu)
+            # ---- postprocess1 (wavenet.py:79-88)
+            K.f16x3_wgrad(p=skip, p_relu=True, q0=h1, dw=G['post1_w'], slab=ws['wslab'], B=B, T=T, Cp=S, Q0=S, taps=[0],
+                          p_scale=hsc('SK'), q0_scale=hsc('DH'), q_total=G['post1_b'], q_seg=dce.view(-1)[L * 2 * R * Tz:], seg_T=Tz,
+                          seg_bstride=cbs, mode=mdh)
+            K.f16x3_out_conv(epi=2, xp=ws['hp'], Cin=S, wp=ws['wpost1t'], net_out=skip, aux0=skip, net_out_planes=ws['gr'],
+                             planes_kc0=0, planes_KC=(S + R) // 8, B=B, T=T, R=S, S=0, w_scale_inv=1.0, x_scale=hsc('DH'),
+                             w_scale=hsc('WH'), out_scale=hsc('G'), out_amax=ham('G'), flag=hflag, mode=mdh)   # skip := d skip, and its planes
+        else:
+            # ---- postprocess2 (wavenet.py:93-96)
+            K.wgrad_gemm(p=h1, p_relu=True, q0=dlog, dw=G['post2_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=Q, taps=[0])
+            K.rowsum(dlog, total=G['post2_b'])
+            K.conv_gemm(x0=dlog, w=Tt['post2_w'], out0=h1, aux0=h1, B=B, T_in=T, T_out=T, M=S, C0=Q, taps=[0],
+                        epilogue=K.EPI_MASK)                       # h1 := d h1 (pre-relu)
+            if self.x3_guard and not self._x3_active:              # fp32 repeat of a step: what the planes would have held
+                K.f16x3_amax(h1, self.x3_amax[self.SL['DH']:self.SL['DH'] + 1])
+            # ---- postprocess1 (wavenet.py:79-88)
+            K.wgrad_gemm(p=skip, p_relu=True, q0=h1, dw=G['post1_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=S, taps=[0])
+            seg_p1 = torch.empty(B, S, Tz, device=self.dev)
+            K.rowsum(h1, seg_out=seg_p1, total=G['post1_b'], seg=ratio)
+            dce[:, L * 2 * R:].copy_(seg_p1)
+            K.conv_gemm(x0=h1, w=Tt['post1_w'], out0=skip, aux0=skip, B=B, T_in=T, T_out=T, M=S, C0=S, taps=[0],
+                        epilogue=K.EPI_MASK)                       # skip := d skip (same for every layer)
         dskip = skip
         ws['bskip'].zero_()
         K.rowsum(dskip, total=ws['bskip'])
@@ -707,11 +775,12 @@ class VQVAE:
         if gbwd_x3:
             K.f16x3_pack_weights(Tt['out_w'], ws['wgb'], S + R, R, R, WS, count=L, scale_dev=sc('WO'), mode=md)
             K.f16x3_pack_weights(Tt['out_w'][L - 1], ws['wgb_top'], S, R, R, WS, scale_dev=sc('WO'), mode=md)       # the top layer has no dnet
-            K.f16x3_split_activations(dskip, ws['gr'], B, S, T, scale=GS, kc0=0, KC=(S + R) // 8, scale_dev=sc('G'),
-                                      amax=am('G'), flag=flag, mode=md)   # one tensor for all layers
+            if not head_x3:      # (the input gradient of postprocess1 wrote them otherwise)
+                K.f16x3_split_activations(dskip, ws['gr'], B, S, T, scale=GS, kc0=0, KC=(S + R) // 8, scale_dev=sc('G'),
+                                          amax=am('G'), flag=flag, mode=md)   # one tensor for all layers
         if calib:
             K.f16x3_amax(dskip, am('G'))
-        if wg_x3:      # the weight-gradient kernels add the per-frame sums of dpre into the condition gradient
+        if wg_x3 and not head_x3:      # the weight-gradient kernels add the per-frame sums of dpre into the condition gradient
             dce[:, :L * 2 * R].zero_()
         side_done = {}
         dnet = dnet_ring[(L - 1) % 3]
@@ -785,8 +854,12 @@ class VQVAE:
             K.rowsum(dce, total=tot)
             G['gated_b'].view(-1).add_(tot[:L * 2 * R])
         # ---- skip start + preprocess (wavenet.py:42-55)
-        K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
-                    C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
+        if head_x3 and gbwd_x3:      # dnet += W_skip0^T dskip over dskip's planes (chunks 0..S/8 of the gradient planes)
+            K.f16x3_out_conv(xp=ws['gr'], xp_KC=(S + R) // 8, Cin=S, wp=ws['wskip0t'], net_in=dnet, net_out=dnet, B=B, T=T, R=R, S=0,
+                             w_scale_inv=1.0, x_scale=sc('G'), w_scale=sc('WH'), mode=md)
+        else:
+            K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
+                        C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
         if wg_x3:      # both operands already have guard scales (layer-0 input planes, gradient planes)
             K.f16x3_wgrad(p=net[0], q0=dskip, dw=G['skip0_w'], slab=ws['wslab'], B=B, T=T, Cp=R, Q0=S, taps=[0],
                           p_scale=sc('X', 0), q0_scale=sc('G'), mode=md)
@@ -933,6 +1006,8 @@ class VQVAE:
                     ws = self.forward(x, spk)
                     for l in range(1, self.L + 1):   # what the layer-input planes would have held
                         K.f16x3_amax(ws['net'][l], self.x3_amax[self.SL['X'] + l:self.SL['X'] + l + 1])
+                    K.f16x3_amax(ws['skip'], self.x3_amax[self.SL['SK']:self.SL['SK'] + 1])
+                    K.f16x3_amax(ws['h1'], self.x3_amax[self.SL['H1']:self.SL['H1'] + 1])
                     self.backward(x, spk, ws)
                     world = self.grad_sync.finish() if self.grad_sync is not None else 1
                 finally:
