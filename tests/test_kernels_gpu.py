@@ -890,6 +890,39 @@ def test_conv_cin1_fwd_and_wgrad(K):
     close(btc(out), r * sc + sh, what='enc1 bn')
 
 
+@pytest.mark.parametrize('T', [2600, 2602])
+def test_conv_cin1_long_rows(K, T):
+    """Rows longer than one 1024-step chunk (the weight-gradient kernel walks them and reduces once), a length that is not
+    a multiple of 4, both strides."""
+    B, F, k = 3, 24, 32
+    x, w, b = rnd(B, T, 1, seed=11), rnd(k, 1, F, seed=12, s=0.2), rnd(F, seed=13)
+    wr = w.clone().requires_grad_(True)
+    yo = R.conv1d_v2(x, wr, b)
+    xb = g(x[:, :, 0])
+    out = torch.empty(B, F, T, device=DEV)
+    K.conv_cin1_fwd(xb, g(w.reshape(k, F)), g(b), out, k=k, stride=1, offset=-(k - 1))
+    close(btc(out), yo, what='preprocess fwd')
+    dy = rnd(B, T, F, seed=14)
+    yo.backward(dy)
+    dw = torch.zeros(k, F, device=DEV)
+    K.conv_cin1_wgrad(xb, bct(dy), dw, k=k, stride=1, offset=-(k - 1))
+    close(dw, wr.grad.reshape(k, F), rtol=1e-3, atol=1e-3, what='preprocess wgrad')
+    k, Fo = 5, 40
+    w1, b1 = rnd(k, 1, Fo, seed=15, s=0.3), rnd(Fo, seed=16, s=0.1)
+    w1r = w1.clone().requires_grad_(True)
+    r = R.keras_conv1d(x, w1r, b1, stride=2, padding='same', relu=True)
+    To = r.shape[1]
+    out = torch.empty(B, Fo, To, device=DEV)
+    K.conv_cin1_fwd(xb, g(w1.reshape(k, Fo)), g(b1), out, k=k, stride=2, offset=-1, relu=True)
+    close(btc(out), r, what='enc1 relu')
+    dy2 = rnd(B, To, Fo, seed=17)
+    r.backward(dy2)
+    dpre = dy2 * (r.detach() > 0)
+    dw1 = torch.zeros(k, Fo, device=DEV)
+    K.conv_cin1_wgrad(xb, bct(dpre), dw1, k=k, stride=2, offset=-1)
+    close(dw1, w1r.grad.reshape(k, Fo), rtol=1e-3, atol=1e-3, what='enc1 wgrad')
+
+
 def test_rowsum_transpose_softmax_adam(K):
     B, Cc, T = 3, 20, 448
     x, y = rnd(B, Cc, T, seed=1), rnd(B, Cc, T, seed=2)

@@ -75,9 +75,10 @@ __global__ void wavenet_inputs_kernel(const float* __restrict__ x, float* __rest
 // ----------------------------------------------------------------------------- Cin == 1 convs
 // wavenet.py:42-44 (preprocess, causal k=32) and encoder.py:15 layer 1 (k=5, stride 2, SAME).
 // Block = 256 threads x 4 consecutive output times for FT output channels; the input window of
-// the block (stride*1024 + k samples) is staged once in LDS and the taps of the block's channels
-// sit in LDS too, so the kernel is bound by its output stream (HBM), not by scalar loads.
-template <int KMAX, int FT>
+// the block (stride*1024 + k samples) is staged once in LDS, every thread keeps ITS window (3*stride + k samples) in
+// registers (STRIDE is a template argument for that; 0 = any stride, window read from LDS tap by tap) and the taps of the
+// block's channels sit in LDS too, so the kernel is bound by its output stream (HBM), not by LDS reads.
+template <int KMAX, int FT, int STRIDE>
 __global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
@@ -102,6 +103,12 @@ __global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(
     const int t0 = tb + 4 * threadIdx.x;
     if (t0 >= T_out) return;
     const int xo = stride * 4 * threadIdx.x;
+    constexpr int WIN = STRIDE > 0 ? 3 * STRIDE + KMAX : 1;
+    float xw[WIN];
+    if (STRIDE > 0) {
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) xw[i] = xs[xo + i];
+    }
     for (int ff = 0; ff < FT; ++ff) {
         const int f = f0 + ff;
         if (f >= F) break;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(
         for (int j = 0; j < KMAX; ++j) {
             const float wv = ws[j * FT + ff];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, xs[xo + stride * e + j], acc[e]);
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, STRIDE > 0 ? xw[STRIDE * e + j] : xs[xo + stride * e + j], acc[e]);
         }
         const size_t ro = ((size_t)b * F + f) * T_out;
         float r[4], y[4];
@@ -137,37 +144,57 @@ __global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(
     }
 }
 
-// dw[j][f] += sum_t x[stride*t+j+offset] * dout[f][t]: same staging; every thread keeps KMAX partial
-// sums for one channel at a time, reduced over the block with wavefront shuffles.
-template <int KMAX>
+// dw[j][f] += sum_{b,t} x[b][stride*t+j+offset] * dout[b][f][t].  One block per (channel f, batch row b): it walks the
+// row in chunks of 1024 output times (same staging of the input window), every thread adds its 4 times x KMAX taps
+// into KMAX register sums, and the block reduces ONCE at the end (wavefront shuffles, LDS, one atomic per tap) -- a
+// reduction per chunk cost more than the products.
+template <int KMAX, int STRIDE>
 __global__ __launch_bounds__(256) void conv_cin1_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dw, int T_in,
     int T_out, int F, int k, int stride, int offset) {
     extern __shared__ float cs[];
     __shared__ float red[4][KMAX];
-    const int f = blockIdx.y, b = blockIdx.z;
-    const int tb = 4 * blockIdx.x * 256;
+    const int f = blockIdx.x, b = blockIdx.y;
     const int win = stride * 1024 + KMAX;
     float* xs = cs;
     const float* xr = x + (size_t)b * T_in;
-    const int i0 = stride * tb + offset;
-    for (int i = threadIdx.x; i < win; i += 256) {
-        const int ti = i0 + i;
-        xs[i] = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
-    }
-    __syncthreads();
-    const int t0 = tb + 4 * threadIdx.x;
     const float* dr = dout + ((size_t)b * F + f) * T_out;
-    float dv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dv[e] = (t0 + e < T_out) ? dr[t0 + e] : 0.0f;
     const int xo = stride * 4 * threadIdx.x;
+    constexpr int WIN = STRIDE > 0 ? 3 * STRIDE + KMAX : 1;
+    float acc[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) acc[j] = 0.0f;
+    for (int tb = 0; tb < T_out; tb += 1024) {
+        const int i0 = stride * tb + offset;
+        __syncthreads();                                  // the previous chunk's window has been read
+        for (int i = threadIdx.x; i < win; i += 256) {
+            const int ti = i0 + i;
+            xs[i] = (ti >= 0 && ti < T_in) ? xr[ti] : 0.0f;
+        }
+        __syncthreads();
+        const int t0 = tb + 4 * threadIdx.x;
+        float dv[4];
+        if (t0 + 3 < T_out && (T_out & 3) == 0) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dr + t0);
+            dv[0] = v[0]; dv[1] = v[1]; dv[2] = v[2]; dv[3] = v[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[e] = (t0 + e < T_out) ? dr[t0 + e] : 0.0f;
+        }
+        float xw[WIN];
+        if (STRIDE > 0) {
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) xw[i] = xs[xo + i];
+        }
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] = fmaf(STRIDE > 0 ? xw[STRIDE * e + j] : xs[xo + stride * e + j], dv[e], acc[j]);
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
-        float v = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v = fmaf(xs[xo + stride * e + j], dv[e], v);
+        float v = acc[j];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if (lane == 0) red[wid][j] = v;
@@ -469,10 +496,12 @@ extern "C" int vqw_conv_cin1_fwd(const float* x, const float* w, const float* bi
     VQW_CHECK(stride <= 4, "vqw_conv_cin1_fwd: stride must be <= 4");
     constexpr int FT = 16;
     dim3 grid(vqw_cdiv(vqw_cdiv(T_out, 4), 256), vqw_cdiv(F, FT), B);
-    if (k <= 8)
-        hipLaunchKernelGGL((conv_cin1_fwd_kernel<8, FT>), grid, dim3(256), (stride * 1024 + 8 + 8 * FT) * sizeof(float), (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
-    else
-        hipLaunchKernelGGL((conv_cin1_fwd_kernel<32, FT>), grid, dim3(256), (stride * 1024 + 32 + 32 * FT) * sizeof(float), (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
+    typedef void (*kfn_t)(const float*, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int);
+    const int kmax = k <= 8 ? 8 : 32;
+    // the model's two shapes keep their window in registers (compile-time stride); anything else goes tap by tap
+    kfn_t kfn = kmax == 8 ? (stride == 2 ? conv_cin1_fwd_kernel<8, FT, 2> : (stride == 1 ? conv_cin1_fwd_kernel<8, FT, 1> : conv_cin1_fwd_kernel<8, FT, 0>))
+                          : (stride == 1 ? conv_cin1_fwd_kernel<32, FT, 1> : conv_cin1_fwd_kernel<32, FT, 0>);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), (stride * 1024 + kmax + kmax * FT) * sizeof(float), (hipStream_t)s, x, w, bias, scale, shift, out, save_r, T_in, T_out, F, k, stride, offset, relu);
     VQW_LAUNCH_CHECK("vqw_conv_cin1_fwd");
     return 0;
 }
@@ -482,11 +511,13 @@ extern "C" int vqw_conv_cin1_wgrad(const float* x, const float* dout, float* dw,
     VQW_CHECK(x && dout && dw, "vqw_conv_cin1_wgrad: null pointer");
     VQW_CHECK(B > 0 && T_in > 0 && T_out > 0 && F > 0 && k >= 1 && k <= 32 && stride >= 1, "vqw_conv_cin1_wgrad: bad shape (k<=32)");
     VQW_CHECK(stride <= 4, "vqw_conv_cin1_wgrad: stride must be <= 4");
-    dim3 grid(vqw_cdiv(vqw_cdiv(T_out, 4), 256), F, B);
-    if (k <= 8)
-        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<8>), grid, dim3(256), (stride * 1024 + 8) * sizeof(float), (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
-    else
-        hipLaunchKernelGGL((conv_cin1_wgrad_kernel<32>), grid, dim3(256), (stride * 1024 + 32) * sizeof(float), (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
+    VQW_CHECK(B <= 65535, "vqw_conv_cin1_wgrad: B must be <= 65535");
+    dim3 grid(F, B);
+    typedef void (*kfn_t)(const float*, const float*, float*, int, int, int, int, int, int);
+    const int kmax = k <= 8 ? 8 : 32;
+    kfn_t kfn = kmax == 8 ? (stride == 2 ? conv_cin1_wgrad_kernel<8, 2> : (stride == 1 ? conv_cin1_wgrad_kernel<8, 1> : conv_cin1_wgrad_kernel<8, 0>))
+                          : (stride == 1 ? conv_cin1_wgrad_kernel<32, 1> : conv_cin1_wgrad_kernel<32, 0>);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), (stride * 1024 + kmax) * sizeof(float), (hipStream_t)s, x, dout, dw, T_in, T_out, F, k, stride, offset);
     VQW_LAUNCH_CHECK("vqw_conv_cin1_wgrad");
     return 0;
 }
