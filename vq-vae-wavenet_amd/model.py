@@ -737,10 +737,6 @@ class VQVAE:
             K.conv_gemm(x0=h1, w=Tt['post1_w'], out0=skip, aux0=skip, B=B, T_in=T, T_out=T, M=S, C0=S, taps=[0],
                         epilogue=K.EPI_MASK)                       # skip := d skip (same for every layer)
         dskip = skip
-        ws['bskip'].zero_()
-        K.rowsum(dskip, total=ws['bskip'])
-        G['out_b'][:, :S] += ws['bskip']
-        G['skip0_b'] += ws['bskip']
         # ---- residual stack, top layer first (wavenet.py:63-74)
         net = ws['net']
         seg_l = torch.empty(B, 2 * R, Tz, device=self.dev)
@@ -860,11 +856,15 @@ class VQVAE:
         else:
             K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
                         C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
-        if wg_x3:      # both operands already have guard scales (layer-0 input planes, gradient planes)
+        ws['bskip'].zero_()      # sum of dskip over batch and time: the bias gradient of skip0 and of every layer's skip half
+        if wg_x3:      # both operands already have guard scales (layer-0 input planes, gradient planes); the sum rides along
             K.f16x3_wgrad(p=net[0], q0=dskip, dw=G['skip0_w'], slab=ws['wslab'], B=B, T=T, Cp=R, Q0=S, taps=[0],
-                          p_scale=sc('X', 0), q0_scale=sc('G'), mode=md)
+                          p_scale=sc('X', 0), q0_scale=sc('G'), q_total=ws['bskip'], mode=md)
         else:
             K.wgrad_gemm(p=net[0], q0=dskip, dw=G['skip0_w'], B=B, T_q=T, T_p=T, Cp=R, Q0=S, taps=[0])
+            K.rowsum(dskip, total=ws['bskip'])
+        G['out_b'][:, :S] += ws['bskip']
+        G['skip0_b'] += ws['bskip']
         K.conv_cin1_wgrad(ws['inputs'], dnet, G['pre_w'], k=self.pre_k, stride=1, offset=-(self.pre_k - 1))
         K.rowsum(dnet, total=G['pre_b'])
         # ---- local condition (wavenet_ops.py:93-101) -> d cond
