@@ -1339,6 +1339,10 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     a.n_nt = (d.Q0 + d.Q1) / 256;
     const int tiles = d.ntaps * (d.Cp / 256) * a.n_nt;
     int nsplit = d.nsplit > 0 ? d.nsplit : vqw_device_cus() / tiles;     // one round of blocks
+    // block id = tile * nsplit + split and consecutive ids go round the 8 XCDs: with nsplit a multiple of 8 all tiles of one K
+    // range sit on the same XCD and share their operand panels in its L2 (tools/wgrad_split_bench.py: gate conv 42 -> 40 splits
+    // 174 -> 160 us, 1x1 85 -> 80 splits 99 -> 97 us, although 16 CUs stay idle)
+    if (d.nsplit <= 0 && nsplit >= 8) nsplit &= ~7;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > a.pairs_total) nsplit = a.pairs_total;
     a.nsplit = nsplit;
