@@ -855,6 +855,7 @@ struct WgArgs {
     int B, T, Cp, Q0, Q1, ntaps;
     int Tp;               // row length of p (= T, or the input length of a stride-2 conv: p index 2 t + shift)
     int p_relu;           // p := max(p, 0) on the way in (the convs behind a relu, wavenet.py:79, 93)
+    int xcd_groups;       // > 0: block -> (tile, split) by XCD-local groups of taps (see the kernel); = (tiles / ntaps) * nsplit
     int shift[VQW_MAX_TAPS];
     int nsplit, pairs_row, pairs_total, n_nt;
     // sums of q over time, formed from the registers that hold q anyway (blocks of the first row tile only):
@@ -888,9 +889,22 @@ template <bool ODD, bool BF, bool S2 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const int tile = blockIdx.x / a.nsplit, split = blockIdx.x - tile * a.nsplit;
-    const int mt = tile / a.n_nt, nt = tile - mt * a.n_nt;
     const int cpt = a.Cp / 256;                       // 256-row tiles per tap
+    int tile, split;
+    if (a.xcd_groups > 0) {
+        // consecutive block ids go round the 8 XCDs: the taps of one (row tile, column tile, K range) -- same q panel, p panels
+        // that are the same cache lines shifted by a few elements -- are given to ONE XCD (slot = id / 8 counts groups x taps)
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int gi = slot / a.ntaps, tp = slot - gi * a.ntaps, g = gi * 8 + x;
+        if (g >= a.xcd_groups) return;                // (whole block, before any barrier)
+        const int mn = g / a.nsplit;                  // (row tile within the tap, column tile)
+        split = g - mn * a.nsplit;
+        tile = (tp * cpt + mn / a.n_nt) * a.n_nt + mn % a.n_nt;
+    } else {
+        tile = blockIdx.x / a.nsplit;
+        split = blockIdx.x - tile * a.nsplit;
+    }
+    const int mt = tile / a.n_nt, nt = tile - mt * a.n_nt;
     const int tap = mt / cpt, c0 = (mt - tap * cpt) * 256;
     const int shift = a.shift[tap];
     const int o0 = nt * 256;
@@ -1364,7 +1378,16 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     const kfn_t kfn = s2 ? wgrad_f16x3_kernel<false, false, true> : ktab[(odd ? 1 : 0) + 2 * (d.mode & 1)];
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-    hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
+    // XCD-local tap groups (xcd_group 1 / 2 = forced on / off).  tools/wgrad_split_bench.py: encoder layer 1 (5 taps, stride 2)
+    // 541 -> 467 us; gate conv d=64 (40 splits) 159 -> 151 us, d=1 184 -> 187 us; with a split count that is not a multiple of 8
+    // the groups of an XCD no longer fill it evenly (42 splits: 255 us)
+    const bool grouped = d.ntaps > 1 && (d.xcd_group == 1 || (d.xcd_group == 0 && (s2 || nsplit % 8 == 0)));
+    int blocks = tiles * nsplit;
+    if (grouped) {
+        a.xcd_groups = (tiles / d.ntaps) * nsplit;
+        blocks = 8 * ((a.xcd_groups + 7) / 8) * d.ntaps;
+    }
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
     const long tap_stride = d.dw_tap_stride > 0 ? (long)d.dw_tap_stride : (long)d.Cp * lddw;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(65536 / 4 / 256, tiles), dim3(256), 0, st, d.slab, d.dw, nsplit, a.n_nt, d.Cp / 256, d.Cp,
                        (long)lddw, tap_stride);

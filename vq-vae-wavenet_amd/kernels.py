@@ -381,7 +381,7 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
 
 def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
                 q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=None,
-                p_stride=1, T_p=None, p_relu=False):
+                p_stride=1, T_p=None, p_relu=False, xcd_group=0):
     """vqw_f16x3_wgrad: dw[j][c][o] += sum_{b,t} p[b][c][p_stride*t+taps[j]] * q[b][o][t] on the fp16x3 engine (slab = scratch;
     p_stride 2: p rows are T_p long, indices outside [0, T_p) are zero padding)."""
     mode = x3_mode(mode)
@@ -395,7 +395,7 @@ def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None
     _need(dw, (len(taps) - 1) * dw_tap_stride + (Cp - 1) * lddw + Q0 + Q1, 'dw')
     _need(slab, 65536, 'slab')
     d = L.F16x3WgradDesc()
-    d.p_stride, d.Tp, d.p_relu = p_stride, T_p, int(bool(p_relu))
+    d.p_stride, d.Tp, d.p_relu, d.xcd_group = p_stride, T_p, int(bool(p_relu)), xcd_group
     d.p, d.q0, d.q1, d.dw, d.slab = p.data_ptr(), q0.data_ptr(), (None if q1 is None else q1.data_ptr()), dw.data_ptr(), slab.data_ptr()
     d.slab_floats = slab.numel()
     d.p_scale, d.q0_scale, d.q1_scale = _slot(p_scale, 'p_scale'), _slot(q0_scale, 'q0_scale'), _slot(q1_scale, 'q1_scale')
