@@ -762,7 +762,7 @@ struct SconvArgs {
 };
 // Block shapes: MR = 4 / DEPTH 1 (128 rows, two blocks per CU), MR = 4 / DEPTH 2 (one block per CU with two stages of requests
 // in flight: launches of <= CUs blocks, where nothing else hides the operand latency), MR = 8 / DEPTH 2 (256 rows).
-template <int MR, int DEPTH>
+template <int MR, int DEPTH, bool DGRAD>
 __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f16x3_kernel(const SconvArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int HB = 32 * MR;
@@ -784,28 +784,40 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
     LoopGeom g;
     g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = d.Cin; g.dilation = 1; g.NB = a.NB; g.xkc0 = 0; g.dir = 1; g.T = T;
     g.m_row0 = mt * HB; g.n0 = n0; g.t0 = 0; g.wks = d.ks;
-    if (!d.dgrad) {
+    if constexpr (!DGRAD) {
         g.ks = d.ks; g.xKC = 2 * d.Cin / 8; g.tj0 = 0; g.tjstep = 1; g.toff = d.pad_left; g.tsgn = -1; g.ts2d = 1;
         f16x3_mainloop<false, MR, true, DEPTH>(acc, smem, g, wv, lane);
         const bool hb = d.bias != nullptr, hs = d.bn_scale != nullptr, sv = d.save_r != nullptr;
         const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);
         const float* sp = hs ? d.bn_scale : reinterpret_cast<const float*>(d.wp);
         const float* hp = hs ? d.bn_shift : reinterpret_cast<const float*>(d.wp);
+        // one 64-bit base per column, 32-bit row offsets inside (out and save_r are < 2 GiB each); the per-row constants are
+        // fetched group by group (64-bit lane addresses per element and constants fetched up front spilled 570 registers)
+        float* po[2];
+        float* pr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t cb = (size_t)bcol[j] * M * T + tcol[j];
+            po[j] = d.out + cb;
+            pr[j] = sv ? d.save_r + cb : d.out + cb;
+        }
+        const float rlo = d.relu ? 0.0f : -INFINITY;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int v4 = 0; v4 < 4; ++v4) {
                 const int m0 = mt * HB + 32 * i + 8 * v4 + 4 * lhi;      // first of this lane's four rows
+                const f32x4 bq = hb ? *reinterpret_cast<const f32x4*>(bp + m0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 sq = hs ? *reinterpret_cast<const f32x4*>(sp + m0) : f32x4{1.f, 1.f, 1.f, 1.f};
+                const f32x4 hq = hs ? *reinterpret_cast<const f32x4*>(hp + m0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float bv = bp[hb ? m0 + e : 0], sc = sp[hs ? m0 + e : 0], sh = hp[hs ? m0 + e : 0];
+                    const int ro = (m0 + e) * T;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const size_t off = ((size_t)bcol[j] * M + m0 + e) * T + tcol[j];
-                        float y = acc[i][j][v4 * 4 + e] * winv + (hb ? bv : 0.0f);
-                        if (d.relu) y = fmaxf(y, 0.0f);
-                        if (sv) d.save_r[off] = y;
-                        d.out[off] = hs ? sc * y + sh : y;
+                        const float y = fmaxf(acc[i][j][v4 * 4 + e] * winv + bq[e], rlo);
+                        if (sv) pr[j][ro] = y;
+                        po[j][ro] = sq[e] * y + hq[e];
                     }
                 }
             }
@@ -816,6 +828,9 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
             g.ks = (d.ks - g.tj0 + 1) / 2;                       // taps of this parity (>= 1 for ks >= 2)
             if (r) __syncthreads();                              // the first run's last stage is still being read
             f16x3_mainloop<false, MR, true, DEPTH>(acc, smem, g, wv, lane);
+            float* pd[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pd[j] = d.out + (size_t)bcol[j] * M * (2 * T) + 2 * tcol[j] + r;
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -824,8 +839,7 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            d.out[((size_t)bcol[j] * M + m0 + e) * (2 * T) + 2 * tcol[j] + r] = acc[i][j][v4 * 4 + e] * winv;
+                        for (int j = 0; j < 2; ++j) pd[j][(m0 + e) * (2 * T)] = acc[i][j][v4 * 4 + e] * winv;
                 }
         }
     }
@@ -1315,7 +1329,8 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     if (shape == 0) shape = (!d.dgrad && d.M % 256 == 0 && (d.M / 256) * nt * 2 > cus) ? 3 : 2;
     VQW_CHECK(shape >= 1 && shape <= 3 && (shape != 3 || d.M % 256 == 0), "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2 or 3 (256-row blocks: M %% 256 == 0)");
     typedef void (*kfn_t)(SconvArgs);
-    const kfn_t kfn = shape == 3 ? sconv_f16x3_kernel<8, 2> : (shape == 2 ? sconv_f16x3_kernel<4, 2> : sconv_f16x3_kernel<4, 1>);
+    const kfn_t kfn = d.dgrad ? (shape == 3 ? sconv_f16x3_kernel<8, 2, true> : (shape == 2 ? sconv_f16x3_kernel<4, 2, true> : sconv_f16x3_kernel<4, 1, true>))
+                              : (shape == 3 ? sconv_f16x3_kernel<8, 2, false> : (shape == 2 ? sconv_f16x3_kernel<4, 2, false> : sconv_f16x3_kernel<4, 1, false>));
     const int mr = shape == 3 ? 8 : 4, lds = (shape == 1 ? 3 : 4) * (mr * 2 + 16) * 1024;      // DEPTH + 2 stages
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_strided_conv: cannot reserve %d bytes of LDS", lds);
