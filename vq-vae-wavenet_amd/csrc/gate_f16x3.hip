@@ -1321,12 +1321,12 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     a.d = d;
     a.NB = d.B * d.T;
     // block shape (d.shape forces one).  Measured on the benchmark's layers (tools/sconv_bench.py, us, shapes 1 / 2 / 3):
-    //   forward  T=1664: 316 / 318 / 252   T=832: 167 / 148 / 222   T=416: 165 / 142 / 224
-    //   dgrad    T=1664: 350 / 327 / 460   T=832: 245 / 157 / 370   T=416: 244 / 146 / 369
-    // -> 256-row blocks for a forward launch that fills more than half of the chip with them, otherwise the deep 128-row shape
+    //   forward  T=1664: 305 / 290 / 230   T=832: 156 / 131 / 194   T=416: 150 / 127 / 194
+    //   dgrad    T=1664: 314 / 314 / 301   T=832: 198 / 145 / 276   T=416: 195 / 135 / 274
+    // -> 256-row blocks for a launch that fills more than half of the chip with them, otherwise the deep 128-row shape
     const int cus = vqw_device_cus(), nt = a.NB / 256;
     int shape = d.shape;
-    if (shape == 0) shape = (!d.dgrad && d.M % 256 == 0 && (d.M / 256) * nt * 2 > cus) ? 3 : 2;
+    if (shape == 0) shape = (d.M % 256 == 0 && (d.M / 256) * nt * 2 > cus) ? 3 : 2;
     VQW_CHECK(shape >= 1 && shape <= 3 && (shape != 3 || d.M % 256 == 0), "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2 or 3 (256-row blocks: M %% 256 == 0)");
     typedef void (*kfn_t)(SconvArgs);
     const kfn_t kfn = d.dgrad ? (shape == 3 ? sconv_f16x3_kernel<8, 2, true> : (shape == 2 ? sconv_f16x3_kernel<4, 2, true> : sconv_f16x3_kernel<4, 1, true>))
