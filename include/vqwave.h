@@ -177,6 +177,11 @@ int vqw_rowsum(const float* x, const float* y, float* seg_out, float* total, flo
  *   dz[b][c][t] = dx[b][c][t] * scale[c] * (r ? (r[b][c][t] > 0) : 1);  dz may alias dx.    */
 int vqw_bn_relu_bwd(const float* dx, const float* r, const float* scale, float* dz, int B,
                     int C, int T, vqw_stream_t s);
+/* The same in one pass with the sums an encoder layer's backward needs (each optional, accumulated):
+ *   dscale[c] += sum_{b,t} dx * y (y = r, or the BatchNorm input of a layer without relu; NULL = 1),
+ *   dbeta[c] += sum_{b,t} dx,  dbias[c] += sum_{b,t} dz.                                                   */
+int vqw_bn_relu_bwd_sums(const float* dx, const float* y, const float* r, const float* scale, float* dz, float* dscale,
+                         float* dbeta, float* dbias, int B, int C, int T, vqw_stream_t s);
 
 /* relu -> BatchNorm(inference affine) in place (encoder.py:15-20), the second pass of a split-K layer:
  *   r[b][c][t] = relu(x) (optional);  x := scale[c]*relu(x) + shift[c]  (scale NULL: x := relu(x))     */

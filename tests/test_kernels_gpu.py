@@ -923,6 +923,24 @@ def test_conv_cin1_long_rows(K, T):
     close(dw1, w1r.grad.reshape(k, Fo), rtol=1e-3, atol=1e-3, what='enc1 wgrad')
 
 
+@pytest.mark.parametrize('T,with_r', [(416, True), (104, False), (37, True)])
+def test_bn_relu_bwd_with_sums(K, T, with_r):
+    """One pass: dz = dx * scale * (r > 0) and the three per-channel sums of an encoder layer's backward (encoder.py:19-20)."""
+    B, Cc = 3, 40
+    dx, y, sc = rnd(B, Cc, T, seed=21), rnd(B, Cc, T, seed=22), rnd(Cc, seed=23)
+    r = torch.relu(y) if with_r else None
+    yy = r if with_r else y
+    dsc0, dbe0, dbi0 = rnd(Cc, seed=24), rnd(Cc, seed=25), rnd(Cc, seed=26)
+    dsc, dbe, dbi = g(dsc0), g(dbe0), g(dbi0)
+    dz = g(dx)
+    K.bn_relu_bwd_sums(dz, g(yy), g(r) if with_r else None, g(sc), dz, dscale=dsc, dbeta=dbe, dbias=dbi)      # in place
+    want = dx * sc[None, :, None] * ((r > 0) if with_r else 1.0)
+    close(dz, want, what='dz')
+    close(dsc, dsc0 + (dx * yy).sum((0, 2)), rtol=1e-4, atol=1e-4, what='d scale')
+    close(dbe, dbe0 + dx.sum((0, 2)), rtol=1e-4, atol=1e-4, what='d beta')
+    close(dbi, dbi0 + want.sum((0, 2)), rtol=1e-4, atol=1e-4, what='d bias')
+
+
 def test_rowsum_transpose_softmax_adam(K):
     B, Cc, T = 3, 20, 448
     x, y = rnd(B, Cc, T, seed=1), rnd(B, Cc, T, seed=2)

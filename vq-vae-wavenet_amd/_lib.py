@@ -120,6 +120,7 @@ SIGNATURES = {
     'vqw_conv_cin1_wgrad': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp]),
     'vqw_rowsum': (_i, [_fp, _fp, _fp, _fp, _f, _i, _i, _i, _i, _fp]),
     'vqw_bn_relu_bwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
+    'vqw_bn_relu_bwd_sums': (_i, [_fp] * 8 + [_i, _i, _i, _fp]),
     'vqw_relu_bn_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     'vqw_mfcc': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _fp]),
     'vqw_transpose': (_i, [_fp, _fp, _i, _i, _i, _fp]),

@@ -326,6 +326,53 @@ __global__ void bn_relu_bwd_kernel(const float* __restrict__ dx, const float* __
     }
 }
 
+// The same with the three sums the backward pass of an encoder layer needs, in ONE pass over dx (and y / r):
+//   dscale[c] += sum_{b,t} dx * y   (y = the relu output, or the BN input of the last layer)
+//   dbeta[c]  += sum_{b,t} dx
+//   dz = dx * scale[c] * (r > 0);   dbias[c] += sum_{b,t} dz   (the conv's bias gradient, optional)
+// One wave per (b, c) row, 16 bytes per lane; three atomics per row.
+__global__ void bn_relu_bwd_sums_kernel(const float* __restrict__ dx, const float* __restrict__ y, const float* __restrict__ r,
+                                        const float* __restrict__ scale, float* __restrict__ dz, float* __restrict__ dscale,
+                                        float* __restrict__ dbeta, float* __restrict__ dbias, int rows, int C, int T) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int c = row % C;
+    const float sc = scale[c];
+    const size_t o = (size_t)row * T;
+    float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if ((T & 3) == 0) {
+        for (int q = lane; q < (T >> 2); q += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dx + o + 4 * q);
+            f32x4 yv = {1.f, 1.f, 1.f, 1.f}, rv = {1.f, 1.f, 1.f, 1.f}, z;
+            if (y) yv = *reinterpret_cast<const f32x4*>(y + o + 4 * q);
+            if (r) rv = (r == y) ? yv : *reinterpret_cast<const f32x4*>(r + o + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1 += v[e] * yv[e];
+                s2 += v[e];
+                z[e] = rv[e] > 0.0f ? v[e] * sc : 0.0f;
+                s3 += z[e];
+            }
+            *reinterpret_cast<f32x4*>(dz + o + 4 * q) = z;
+        }
+    } else {
+        for (int t = lane; t < T; t += 64) {
+            const float v = dx[o + t], yv = y ? y[o + t] : 1.0f, rv = r ? r[o + t] : 1.0f;
+            const float z = rv > 0.0f ? v * sc : 0.0f;
+            s1 += v * yv; s2 += v; s3 += z;
+            dz[o + t] = z;
+        }
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { s1 += __shfl_xor(s1, k); s2 += __shfl_xor(s2, k); s3 += __shfl_xor(s3, k); }
+    if (lane == 0) {
+        if (dscale) unsafeAtomicAdd(dscale + c, s1);
+        if (dbeta) unsafeAtomicAdd(dbeta + c, s2);
+        if (dbias) unsafeAtomicAdd(dbias + c, s3);
+    }
+}
+
 // ----------------------------------------------------------------------------- relu/BN forward
 // Second pass of a split-K encoder layer (encoder.py:15-20): x holds conv + bias; r = relu(x) is saved for the
 // backward pass, x := scale[c] * r + shift[c] (BatchNorm in inference mode).
@@ -555,6 +602,18 @@ extern "C" int vqw_bn_relu_bwd(const float* dx, const float* r, const float* sca
     const size_t n = (size_t)B * C * T;
     hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, dx, r, scale, dz, C, T, n);
     VQW_LAUNCH_CHECK("vqw_bn_relu_bwd");
+    return 0;
+}
+
+extern "C" int vqw_bn_relu_bwd_sums(const float* dx, const float* y, const float* r, const float* scale, float* dz, float* dscale,
+                                    float* dbeta, float* dbias, int B, int C, int T, vqw_stream_t s) {
+    VQW_CHECK(dx && scale && dz && B > 0 && C > 0 && T > 0, "vqw_bn_relu_bwd_sums: bad arguments");
+    VQW_CHECK((T & 3) != 0 || ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y) |
+                                reinterpret_cast<uintptr_t>(r)) & 15u) == 0, "vqw_bn_relu_bwd_sums: tensors must be 16-byte aligned");
+    const int rows = B * C;
+    hipLaunchKernelGGL(bn_relu_bwd_sums_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, dx, y, r, scale, dz, dscale, dbeta, dbias,
+                       rows, C, T);
+    VQW_LAUNCH_CHECK("vqw_bn_relu_bwd_sums");
     return 0;
 }
 

@@ -182,6 +182,23 @@ def bn_relu_bwd(dx, r, scale, dz):
     L.check(L.lib().vqw_bn_relu_bwd(L.ptr(dx), L.ptr(r), L.ptr(scale), L.ptr(dz), B, Cc, T, L.stream()))
 
 
+def bn_relu_bwd_sums(dx, y, r, scale, dz, *, dscale=None, dbeta=None, dbias=None):
+    """dz = dx * scale[c] * (r > 0) (r None: no mask) and, in the same pass, dscale[c] += sum dx * y, dbeta[c] += sum dx,
+    dbias[c] += sum dz (each optional)."""
+    B, Cc, T = dx.shape
+    L.require_cuda(dx, scale, dz)
+    _need(scale, Cc, 'scale')
+    _need(dz, dx.numel(), 'dz')
+    for name, t in (('y', y), ('r', r)):
+        if t is not None:
+            _need(t, dx.numel(), name)
+    for name, t in (('dscale', dscale), ('dbeta', dbeta), ('dbias', dbias)):
+        if t is not None:
+            _need(t, Cc, name)
+    L.check(L.lib().vqw_bn_relu_bwd_sums(L.ptr(dx), L.ptr(y), L.ptr(r), L.ptr(scale), L.ptr(dz), L.ptr(dscale), L.ptr(dbeta),
+                                         L.ptr(dbias), B, Cc, T, L.stream()))
+
+
 def relu_bn_fwd(x, r, scale, shift):
     """In place: r = relu(x) (optional), x = scale[c]*relu(x) + shift[c]."""
     B, Cc, T = x.shape

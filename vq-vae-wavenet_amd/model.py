@@ -890,11 +890,10 @@ class VQVAE:
         sc, dsc = ws['scale'], ws['dscale']
         dsc.zero_()
         dz = ws['dz']
-        K.rowsum(dz, y=ws['y6'], total=dsc[6 * F:])
-        K.rowsum(dz, total=G['bn_beta'][6 * F:])
-        K.bn_relu_bwd(dz, None, sc[6 * F:], dz)                      # dz := d(conv6 output)
+        # BatchNorm / relu backward with its three sums (d scale, d beta, the conv's bias gradient) in one pass per layer
+        K.bn_relu_bwd_sums(dz, ws['y6'], None, sc[6 * F:], dz, dscale=dsc[6 * F:], dbeta=G['bn_beta'][6 * F:],
+                           dbias=G['enc_b6'])                        # dz := d(conv6 output)
         K.wgrad_gemm(p=ws['X'][5], q0=dz, dw=G['enc_w6'], B=B, T_q=Tz, T_p=Tz, Cp=F, Q0=D, taps=[0])
-        K.rowsum(dz, total=G['enc_b6'])
         K.conv_gemm(x0=dz, w=Tt['enc_w6'], out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
@@ -910,13 +909,13 @@ class VQVAE:
         for i in range(5, -1, -1):
             dX, r = ws['dX'][i], ws['r'][i]
             Ti = ws['Tl'][i]
-            K.rowsum(dX, y=r, total=dsc[i * F:(i + 1) * F])
-            K.rowsum(dX, total=G['bn_beta'][i * F:(i + 1) * F])
-            K.bn_relu_bwd(dX, r, sc[i * F:(i + 1) * F], dX)          # dX := d(conv_i output)
             Tin = ws['Tl'][i - 1] if i > 0 else T
             pl, _ = same_pads(Tin, 5, 2)
             on_c = i in ex3
             on_w = wg3 and 1 <= i <= 3 and Ti % 32 == 0 and Tin == 2 * Ti and B * F * Tin * 4 < (1 << 31)
+            K.bn_relu_bwd_sums(dX, r, r, sc[i * F:(i + 1) * F], dX, dscale=dsc[i * F:(i + 1) * F],
+                               dbeta=G['bn_beta'][i * F:(i + 1) * F],
+                               dbias=None if on_w else G['enc_b'][i])   # dX := d(conv_i output); (the engine's wgrad sums the bias itself)
             if on_c or on_w:
                 K.f16x3_amax(dX, ea[3 + i:4 + i], flag=flag)
                 K.f16x3_update_scales(ea[3 + i:4 + i], es[3 + i:4 + i], target_exp=13, flag=flag)
@@ -934,7 +933,6 @@ class VQVAE:
                                   taps=[j - pl for j in range(5)], p_scale=es[i:i + 1], q0_scale=es[3 + i:4 + i], p_stride=2, T_p=Tin,
                                   q_total=G['enc_b'][i], mode=0)
                 else:
-                    K.rowsum(dX, total=G['enc_b'][i])
                     if i == 0:
                         K.conv_cin1_wgrad(x, dX, G['enc_w0'], k=5, stride=2, offset=-pl)
                     else:
