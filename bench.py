@@ -192,8 +192,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)     # (the first steps allocate workspaces and settle the guard scales)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--length', type=int, default=6656)
     ap.add_argument('--gen-steps', type=int, default=8192, help='AR samples to generate for the generation rate (SURVEY 8(d): L >= 8192)')
