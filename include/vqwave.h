@@ -419,7 +419,9 @@ typedef struct vqw_f16x3_out_desc {
     const float* cond;
     int64_t cond_bstride;
     int32_t cond_T;
-    int32_t flags;
+    int32_t flags;         /* bit 0 (epi 2): planes hold relu(net_out).  bit 1 (epi 1): aux0 is the layer's gated OUTPUT tanh * sigmoid instead
+                            * of tanh (a forward pass that does not store tanh: vqw_f16x3_gate_conv with save0 = NULL writes 54 MB less
+                            * per layer); the kernel forms tanh = aux0 / aux1, 0 where the sigmoid underflowed                       */
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 

@@ -722,6 +722,40 @@ def test_wgrad_f16x3_relu_operand(K):
     assert (dw.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
 
 
+@pytest.mark.parametrize('half', [0, 1])
+def test_gate_backward_f16x3_from_tanh_or_from_gated(K, half):
+    """vqw_f16x3_out_conv epi 1 against fp64: dpre = {dg sg (1 - th^2), dg th sg (1 - sg)}, dg = W^T [dskip; dnet]; with aux0 = tanh
+    (saved by the forward pass) and with aux0 = tanh * sigmoid (a forward pass that did not store tanh), including sigmoids that
+    underflowed to zero."""
+    B, T, R, S = 2, 512, 256, 256
+    gen = torch.Generator().manual_seed(51)
+    dcat = (torch.randn(B, S + R, T, generator=gen) * 1e-5).to(DEV)
+    w = (torch.randn(S + R, R, generator=gen) * 0.05).to(DEV)
+    xf, xg = torch.randn(B, R, T, generator=gen).to(DEV) * 2, torch.randn(B, R, T, generator=gen).to(DEV) * 3
+    xg[:, ::7, ::5] = -200.0                                              # sigmoid == 0 exactly
+    th, sg = torch.tanh(xf), torch.sigmoid(xg)
+    gated = th * sg
+    md = K.X3_HALF_BLOCKS if half else 0
+    sc = torch.tensor([2.0 ** 28, 64.0, 2.0 ** 26], device=DEV)
+    gr = torch.empty(2 * B * (S + R) * T, dtype=torch.float16, device=DEV)
+    wp = torch.empty(2 * (S + R) * R, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(dcat, gr, B, S + R, T, scale_dev=sc[0:1], mode=md)
+    K.f16x3_pack_weights(w, wp, S + R, R, R, 1.0, scale_dev=sc[1:2], mode=md)
+    dg = torch.einsum('kc,bkt->bct', w.double(), dcat.double())
+    want = torch.cat([dg * sg.double() * (1 - th.double() ** 2), dg * th.double() * sg.double() * (1 - sg.double())], 1)
+    for aux0, flag_g in ((th, False), (gated, True)):
+        dpre = torch.empty(B, 2 * R, T, device=DEV)
+        planes = torch.empty(2 * B * 2 * R * T, dtype=torch.float16, device=DEV)
+        K.f16x3_out_conv(epi=1, xp=gr, Cin=S + R, wp=wp, aux0=aux0, aux1=sg, net_out=dpre, net_out_planes=planes, B=B, T=T, R=R, S=0,
+                         w_scale_inv=1.0, x_scale=sc[0:1], w_scale=sc[1:2], out_scale=sc[2:3], aux0_is_gated=flag_g, mode=md)
+        assert torch.isfinite(dpre).all()
+        err = (dpre.double() - want).abs().max().item() / want.abs().max().item()
+        assert err <= (2e-6 if flag_g else 1e-6), 'aux0 %s: %.3e of max' % ('gated' if flag_g else 'tanh', err)
+        pl = planes.view(2, 2 * R // 8, B * T, 8).double().sum(0) / 2.0 ** 26
+        got_p = pl.permute(1, 0, 2).reshape(B, T, 2 * R).permute(0, 2, 1)
+        assert (got_p - want).abs().max().item() <= 3e-6 * want.abs().max().item()
+
+
 def test_wgrad_f16x3_full_size_matches_fp32_engine(K):
     """The benchmark's shapes (B=8, T=6656: 1664 stage pairs over 42 / 85 K splits): gate-conv and 1x1 weight gradients
     against the fp32 engine's wgrad kernel and fp64 samples."""

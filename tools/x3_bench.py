@@ -65,6 +65,8 @@ N = B * T
 for d in (1, 64):
     timeit('gate conv d=%d' % d, lambda: K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save0=s0, save1=s1, B=B, T=T, R=R, ks=ks, dilation=d,
                                                            w_scale_inv=1 / 256.0, out_planes=gp), 2.0 * N * ks * R * 2 * R)
+timeit('gate conv d=64, tanh not saved', lambda: K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save1=s1, B=B, T=T, R=R, ks=ks, dilation=64,
+                                                                    w_scale_inv=1 / 256.0, out_planes=gp), 2.0 * N * ks * R * 2 * R)
 timeit('residual 1x1 (+planes)', lambda: K.f16x3_out_conv(xp=gp, wp=wres, net_in=net, net_out=net2, net_out_planes=xp, B=B, T=T, R=R, S=0,
                                                           w_scale_inv=1 / 256.0), 2.0 * N * R * R)
 timeit('gate backward', lambda: K.f16x3_out_conv(epi=1, xp=gr, Cin=S + R, xp_KC=(S + R) // 8, wp=wgb, aux0=th, aux1=sg, net_out=dpre2,

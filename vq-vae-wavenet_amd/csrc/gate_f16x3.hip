@@ -709,6 +709,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
     float gmax = 0.0f;
     bool gbad = false;
     const int PKC = d.planes_KC > 0 ? d.planes_KC : 2 * R / 8;
+    const bool from_gated = (d.flags & 2) != 0;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -725,6 +726,12 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { th[j][e] = pt[e * T + 32 * j]; sg[j][e] = pg[e * T + 32 * j]; }
+            if (from_gated) {       // aux0 holds tanh * sigmoid (the forward pass did not save tanh): tanh = gated / sigmoid, 0 where sigmoid underflowed
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) th[j][e] = sg[j][e] > 0.0f ? th[j][e] * __builtin_amdgcn_rcpf(sg[j][e]) : 0.0f;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll

@@ -289,7 +289,8 @@ def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mo
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
                    net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
                    planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None, x_scale=None, w_scale=None,
-                   out_scale=None, out_amax=None, flag=None, mode=None, cond=None, cond_T=0, cond_bstride=0, relu_planes=False):
+                   out_scale=None, out_amax=None, flag=None, mode=None, cond=None, cond_T=0, cond_bstride=0, relu_planes=False,
+                   aux0_is_gated=False):
     """vqw_f16x3_out_conv; epi 0: skip rows += / residual rows = net_in + W x + b; epi 1: gate backward; epi 2: the 1x1 convs
     around the stack: net_out = (aux0 > 0) * (net_in + W x + bias + cond), planes of net_out or relu(net_out)."""
     mode = x3_mode(mode)
@@ -332,7 +333,7 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     if cond is not None:
         _need(cond, (B - 1) * cond_bstride + R * cond_T, 'cond')
         d.cond, d.cond_T, d.cond_bstride = cond.data_ptr(), cond_T, cond_bstride
-    d.flags = 1 if relu_planes else 0
+    d.flags = (1 if relu_planes else 0) | (2 if aux0_is_gated else 0)
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 
 

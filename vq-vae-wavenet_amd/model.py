@@ -528,6 +528,9 @@ class VQVAE:
         flag = self.x3_flag if gd else None
         WS = 1.0 if gd else 256.0          # guarded: the weight scale lives on the device (exact max-abs of this step's weights)
         head_x3 = ws['head_x3'] = bool(gd and self.head_x3 and 'hp' in ws and T % 32 == 0)
+        # the guarded engine's gate backward forms tanh = gated / sigmoid itself: tanh is not stored (54 MB less per layer and gate
+        # conv, 166 -> 157 us); VQW_SAVE_TANH=1 stores it
+        drop_th = ws['th_dropped'] = bool(gd and self.gbwd_f16x3 and os.environ.get('VQW_SAVE_TANH', '0') != '1')
         if gd:
             K.f16x3_amax(P['gated_w'], am('WG'), flag=flag)
             K.f16x3_amax(P['out_w'], am('WO'), flag=flag)
@@ -560,7 +563,7 @@ class VQVAE:
             if f16x3:
                 if (l == 0 and not head_x3) or not f16x3_out:
                     K.f16x3_split_activations(net[l], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
-                K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if save else None,
+                K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if (save and not drop_th) else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
                                   cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T=T, R=R, ks=self.ks,
                                   dilation=d, w_scale_inv=1.0 / WS, out_planes=ws['gp'] if f16x3_out else None,
@@ -764,6 +767,9 @@ class VQVAE:
         GS = 1.0 if gd else float(2 ** 20)      # guarded: the gradient scales live on the device
         WS = 1.0 if gd else 256.0
         wg_x3 = full and gbwd_x3 and T % 32 == 0 and os.environ.get('VQW_WGRAD_X3', '1') != '0'
+        th_dropped = bool(ws.get('th_dropped'))
+        if th_dropped and not gbwd_x3:
+            raise RuntimeError('the forward pass did not store tanh but gate backward is not on the fp16x3 engine')
         if wg_x3 and 'wslab' not in ws:
             ws['wslab'] = torch.empty(256 * 65536, device=self.dev)      # partial 256x256 tiles of one launch (tiles x K splits <= CUs)
         if dgrad_x3:
@@ -789,7 +795,8 @@ class VQVAE:
                 main.wait_event(side_done[l + 2])            # dpre[l % 2] and dnet[(l - 1) % 3] are free again
             if gbwd_x3:
                 K.f16x3_out_conv(epi=1, xp=ws['gr'], Cin=S if top else S + R, xp_KC=(S + R) // 8,
-                                 wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=ws['th'][l], aux1=ws['sg'][l], net_out=dpre,
+                                 wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=ws['gated'][l] if th_dropped else ws['th'][l],
+                                 aux0_is_gated=th_dropped, aux1=ws['sg'][l], net_out=dpre,
                                  net_out_planes=ws['dp'], plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (WS * GS),
                                  x_scale=sc('G'), w_scale=sc('WO'), out_scale=sc('DP', l), out_amax=am('DP', l), flag=flag, mode=md)
             else:
