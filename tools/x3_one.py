@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few launches of ONE kernel of the fp16x3 engine at the benchmark shape, for rocprofv3 --pmc passes.
-usage: x3_one.py <gate|wgrad> [dilation]"""
+usage: x3_one.py <gate|gate_nosave|wgrad> [dilation]   (gate_nosave: tanh not stored, as the default engine runs it)"""
 import importlib
 import os
 import sys
@@ -26,8 +26,8 @@ K.f16x3_pack_gate_weights(gw, wp, ks, R, 2 * R, 256.0)
 out, s0, s1 = (torch.empty(B, R, T, device=dev) for _ in range(3))
 slab, dw = torch.empty(256 * 65536, device=dev), torch.zeros(ks, R, 2 * R, device=dev)
 for _ in range(5):
-    if what == 'gate':
-        K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save0=s0, save1=s1, bias=bias, cond=cond, cond_T=T // 64, B=B, T=T, R=R, ks=ks,
+    if what in ('gate', 'gate_nosave'):
+        K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save0=None if what == 'gate_nosave' else s0, save1=s1, bias=bias, cond=cond, cond_T=T // 64, B=B, T=T, R=R, ks=ks,
                           dilation=d, w_scale_inv=1 / 256.0, out_planes=gp)
     else:
         K.f16x3_wgrad(p=net, q0=dpre, dw=dw, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, taps=[-2 * d, -d, 0])
