@@ -262,8 +262,8 @@ def f16x3_update_scales(amax, scale, *, target_exp, reset=True, flag=None):
 
 
 def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_dev=None, amax=None, flag=None, mode=None):
-    mode = x3_mode(mode)
     """scale * scale_dev * x [B][C][T] fp32 -> planes [2][KC or C/8][B*T][8] fp16, chunks kc0..."""
+    mode = x3_mode(mode)
     _need(x, B * Cc * T, 'x')
     _need_planes(planes, 2 * B * T * (KC * 8 if KC else Cc), 'planes')
     L.check(L.lib().vqw_f16x3_split_activations(L.ptr(x), L.ptr(planes), B, Cc, T, float(scale), kc0, KC, _slot(scale_dev, 'scale_dev'),
@@ -271,16 +271,16 @@ def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_d
 
 
 def f16x3_pack_gate_weights(w, planes, ks, R, ldw, scale, count=1, scale_dev=None, mode=None):
-    mode = x3_mode(mode)
     """`count` layers back to back in `w` ([count][ks][R][ldw]) and in `planes`."""
+    mode = x3_mode(mode)
     _need(w, (count - 1) * ks * R * ldw + (ks * R - 1) * ldw + 2 * R, 'w')
     _need_planes(planes, count * 2 * ks * R * 2 * R, 'planes')
     L.check(L.lib().vqw_f16x3_pack_gate_weights(L.ptr(w), L.ptr(planes), ks, R, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), mode, L.stream()))
 
 
 def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mode=None):
-    mode = x3_mode(mode)
     """w [count][K][ldw] fp32 -> planes [count][2][K/8][M][8] fp16 of scale * scale_dev * w."""
+    mode = x3_mode(mode)
     _need(w, (count - 1) * Kd * ldw + (Kd - 1) * ldw + M, 'w')
     _need_planes(planes, count * 2 * Kd * M, 'planes')
     L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), mode, L.stream()))
