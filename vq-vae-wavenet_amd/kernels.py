@@ -254,6 +254,8 @@ def f16x3_amax(x, amax, *, rows=None, cols=None, ld=None, mstride=0, count=1, fl
 
 
 def f16x3_update_scales(amax, scale, *, target_exp, reset=True, flag=None):
+    """scale[i] = the power of two that puts amax[i] into [2^(target_exp-1), 2^target_exp) (slots that saw nothing keep their scale);
+    reset: amax[i] = 0 afterwards; a non-finite amax raises `flag`."""
     n = amax.numel()
     if amax.dtype != torch.int32 or scale.dtype != torch.float32 or scale.numel() != n:
         raise ValueError('amax int32 [n], scale float32 [n]')
@@ -365,6 +367,8 @@ def f16x3_strided_conv(*, xp, wp, out, B, T, Cin, M, ks, pad_left, w_scale_inv=1
 def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=None, cond=None, cond_T=0,
                     cond_bstride=0, save0=None, save1=None, out_planes=None, out_planes_kc0=0, out_planes_KC=0, x_scale=None,
                     w_scale=None, mode=None):
+    """vqw_f16x3_gate_conv: dilated causal conv over the layer input planes + bias + upsampled condition, tanh(filter) * sigmoid(gate)
+    -> out0 (and as planes), tanh / sigmoid saved for the backward pass when save0 / save1 are given."""
     mode = x3_mode(mode)
     _need_planes(xp, 2 * B * R * T, 'xp')
     _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
