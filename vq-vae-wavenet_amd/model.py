@@ -945,6 +945,9 @@ class VQVAE:
                     else:
                         K.wgrad_gemm(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], B=B, T_q=Ti, T_p=Tin, Cp=F, Q0=F, p_stride=2,
                                      taps=[j - pl for j in range(5)])
+                if self.grad_sync is not None and i >= 2:      # this layer's kernel gradient (11.8 MB) is final: exchange it under
+                    ew, ne = self.seg_off['enc_w'][0], 5 * F * F   # the rest of the encoder backward
+                    self.grad_sync.bucket_ready(ew + (i - 1) * ne, ew + i * ne)
             if i == 0:
                 break
             if on_c:
@@ -968,8 +971,10 @@ class VQVAE:
         dsc.addcmul_(self.bn_mean, G['bn_beta'], value=-1.0)         # shift = beta - mean*scale
         torch.mul(dsc, torch.rsqrt(self.bn_var + BN_EPS), out=dsc)
         G['bn_gamma'] += dsc
-        if self.grad_sync is not None:
-            self.grad_sync.bucket_ready(0, self.seg_off['pre_w'][0])
+        if self.grad_sync is not None:      # what the per-layer buckets above left: the first layers' kernels, biases, BatchNorm, codebook
+            ew, ne = self.seg_off['enc_w'][0], 5 * F * F
+            self.grad_sync.bucket_ready(0, ew + ne)
+            self.grad_sync.bucket_ready(ew + 5 * ne, self.seg_off['pre_w'][0])
 
     # ------------------------------------------------------------------ optimiser
     def lr_at(self, step):

@@ -1,7 +1,8 @@
 """Data-parallel gradient exchange: one process per GPU, RCCL (torch.distributed 'nccl') sum
 all-reduce of the flat fp32 gradient buffer over xGMI, in buckets that are launched on a side
-stream as soon as backward has finished writing them, so the exchange of the decoder gradients
-(81 MB of 140.6 MB) overlaps the encoder backward.  The reference has no multi-GPU code
+stream as soon as backward has finished writing them: the decoder gradients (81 MB of 140.6 MB) overlap the
+encoder backward, the encoder's 11.8 MB kernels follow layer by layer as their weight gradients finish, so only
+the first layers' gradients (12 MB) are exchanged after the last kernel of the step.  The reference has no multi-GPU code
 (SURVEY.md 2.1); training shards over batch, all losses are means, BN uses moving statistics,
 so averaging the per-rank gradients reproduces the full-batch step.
 """
