@@ -996,7 +996,7 @@ class VQVAE:
 
     def train_step(self, x, spk):
         """One sess.run(train_op) (train.py:104-114).  With self.grad_sync set (data parallel)
-        the flat gradient is sum-all-reduced over RCCL in two overlapped buckets and averaged.
+        the flat gradient is sum-all-reduced over RCCL in buckets that overlap the backward pass, and averaged.
         Guarded fp16x3 engine: the step's range flag is read before the optimiser runs (one host sync per step); a
         step whose planes left fp16's range is repeated on the fp32 engine, which also measures the max-abs values the
         next step's scales come from."""
