@@ -3,7 +3,7 @@
     RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_worker.py <out_dir> <backend>
 
 Builds the tiny model with the shared weights, takes its contiguous shard of the shared 4-row batch, runs ONE
-model.train_step with parallel.GradAllReduce attached (the model's own two buckets, the side-stream join before
+model.train_step with parallel.GradAllReduce attached (the model's own buckets, the side-stream join before
 bucket_ready, the 1/world scaling inside Adam) and writes the summed flat gradient and the stepped parameters.
 Several ranks share ONE GPU here, so the backend is gloo (RCCL refuses two ranks on one device).
 """
