@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few launches of ONE kernel of the fp16x3 engine at the benchmark shape, for rocprofv3 --pmc passes.
-usage: x3_one.py <gate|gate_nosave|wgrad> [dilation]   (gate_nosave: tanh not stored, as the default engine runs it)"""
+usage: x3_one.py <gate|gate_nosave|wgrad|sconv|sconv_dgrad|wgrad_s2> [dilation]   (gate_nosave: tanh not stored, as the default engine runs it)"""
 import importlib
 import os
 import sys
@@ -25,6 +25,30 @@ K.f16x3_split_activations(net, xp, B, R, T)
 K.f16x3_pack_gate_weights(gw, wp, ks, R, 2 * R, 256.0)
 out, s0, s1 = (torch.empty(B, R, T, device=dev) for _ in range(3))
 slab, dw = torch.empty(256 * 65536, device=dev), torch.zeros(ks, R, 2 * R, device=dev)
+if what in ('sconv', 'sconv_dgrad', 'wgrad_s2'):      # encoder layer 1: 768 -> 768, k=5, stride 2, T 3328 -> 1664
+    F, To = 768, 1664
+    x, dy = torch.randn(B, F, 2 * To, device=dev), torch.randn(B, F, To, device=dev) * 1e-5
+    w = torch.randn(5, F, F, device=dev) * 0.02
+    ep = torch.empty(2 * B * F * 2 * To, dtype=torch.float16, device=dev)
+    ewp = torch.empty(2 * 5 * F * F, dtype=torch.float16, device=dev)
+    o1, r1, dx = torch.empty(B, F, To, device=dev), torch.empty(B, F, To, device=dev), torch.empty(B, F, 2 * To, device=dev)
+    bias3 = torch.randn(F, device=dev)
+    dw5 = torch.zeros(5, F, F, device=dev)
+    if what == 'sconv':
+        K.f16x3_split_activations(x, ep, B, F, 2 * To, mode=K.X3_S2D)
+    else:
+        K.f16x3_split_activations(dy, ep, B, F, To, scale=2.0 ** 20, mode=0)
+    K.f16x3_pack_weights(w, ewp, 5 * F, F, F, 16.0, mode=0)
+    for _ in range(5):
+        if what == 'sconv':
+            K.f16x3_strided_conv(xp=ep, wp=ewp, out=o1, save_r=r1, B=B, T=To, Cin=F, M=F, ks=5, pad_left=1, bias=bias3, bn_scale=bias3,
+                                 bn_shift=bias3, relu=True, w_scale_inv=1 / 16.0)
+        elif what == 'sconv_dgrad':
+            K.f16x3_strided_conv(xp=ep, wp=ewp, out=dx, B=B, T=To, Cin=F, M=F, ks=5, pad_left=1, dgrad=True, w_scale_inv=2.0 ** -24)
+        else:
+            K.f16x3_wgrad(p=x, q0=dy, dw=dw5, slab=slab, B=B, T=To, Cp=F, Q0=F, taps=[j - 1 for j in range(5)], p_stride=2, T_p=2 * To, mode=0)
+    torch.cuda.synchronize()
+    sys.exit(0)
 for _ in range(5):
     if what in ('gate', 'gate_nosave'):
         K.f16x3_gate_conv(xp=xp, wp=wp, out0=out, save0=None if what == 'gate_nosave' else s0, save1=s1, bias=bias, cond=cond, cond_T=T // 64, B=B, T=T, R=R, ks=ks,
