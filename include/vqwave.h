@@ -445,7 +445,7 @@ typedef struct vqw_f16x3_sconv_desc {
     float w_scale_inv;
     int32_t B, T, Cin, M, ks, pad_left, relu, dgrad;
     int32_t shape;          /* 0 = by how the launch fills the chip; 1: 128-row blocks, two per CU; 2: 128-row blocks, one per
-                             * CU with deeper prefetch; 3: 256-row blocks (M % 256 == 0)                                    */
+                             * CU with deeper prefetch; 3: 256-row blocks (M % 256 == 0); 4: 192-row blocks (M % 192 == 0)    */
 } vqw_f16x3_sconv_desc;
 int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* d, vqw_stream_t s);
 

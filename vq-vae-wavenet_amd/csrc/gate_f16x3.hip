@@ -254,6 +254,9 @@ struct OutArgs {
 #define VQW_WG_PAT_B 2      // ... and address computations / requests per MFMA in the second stage
 #endif
 
+#ifndef VQW_SCONV_192
+#define VQW_SCONV_192 1       // strided conv: 192-row blocks where they fill more CUs than 256-row blocks (tools/sconv_bench.py)
+#endif
 #ifndef VQW_X3_PAT_MEM
 #define VQW_X3_PAT_MEM 1      // issue pattern of the conv main loop: LDS / global-memory instructions per MFMA ...
 #define VQW_X3_PAT_ALU 2      // ... and address computations per MFMA (tools/x3_bench.py: 1/2 measured best)
@@ -1327,18 +1330,22 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     SconvArgs a;
     a.d = d;
     a.NB = d.B * d.T;
-    // block shape (d.shape forces one).  Measured on the benchmark's layers (tools/sconv_bench.py, us, shapes 1 / 2 / 3):
-    //   forward  T=1664: 305 / 290 / 230   T=832: 156 / 131 / 194   T=416: 150 / 127 / 194
-    //   dgrad    T=1664: 314 / 314 / 301   T=832: 198 / 145 / 276   T=416: 195 / 135 / 274
+    // block shape (d.shape forces one).  Measured on the benchmark's layers (tools/sconv_bench.py, us, shapes 1 / 2 / 3 / 4):
+    //   forward  T=1664: 299 / 290 / 228 / 196   T=832: 154 / 129 / 196 / 155   T=416: 150 / 125 / 196 / 152
+    //   dgrad    T=1664: 314 / 311 / 303 / 236   T=832: 198 / 142 / 275 / 184   T=416: 196 / 134 / 273 / 182
     // -> 256-row blocks for a launch that fills more than half of the chip with them, otherwise the deep 128-row shape
     const int cus = vqw_device_cus(), nt = a.NB / 256;
     int shape = d.shape;
     if (shape == 0) shape = (d.M % 256 == 0 && (d.M / 256) * nt * 2 > cus) ? 3 : 2;
-    VQW_CHECK(shape >= 1 && shape <= 3 && (shape != 3 || d.M % 256 == 0), "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2 or 3 (256-row blocks: M %% 256 == 0)");
+    // 192-row blocks where they fill more CUs than 256-row blocks without a second round (768 rows x 52 column tiles: 208 blocks
+    // instead of 156 on 256 CUs)
+    if (d.shape == 0 && shape == 3 && d.M % 192 == 0 && (d.M / 192) * nt <= cus && VQW_SCONV_192) shape = 4;
+    VQW_CHECK(shape >= 1 && shape <= 4 && (shape != 3 || d.M % 256 == 0) && (shape != 4 || d.M % 192 == 0),
+              "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2, 3 (256-row blocks: M %% 256 == 0) or 4 (192-row blocks: M %% 192 == 0)");
     typedef void (*kfn_t)(SconvArgs);
-    const kfn_t kfn = d.dgrad ? (shape == 3 ? sconv_f16x3_kernel<8, 2, true> : (shape == 2 ? sconv_f16x3_kernel<4, 2, true> : sconv_f16x3_kernel<4, 1, true>))
-                              : (shape == 3 ? sconv_f16x3_kernel<8, 2, false> : (shape == 2 ? sconv_f16x3_kernel<4, 2, false> : sconv_f16x3_kernel<4, 1, false>));
-    const int mr = shape == 3 ? 8 : 4, lds = (shape == 1 ? 3 : 4) * (mr * 2 + 16) * 1024;      // DEPTH + 2 stages
+    const kfn_t kfn = d.dgrad ? (shape == 4 ? sconv_f16x3_kernel<6, 2, true> : (shape == 3 ? sconv_f16x3_kernel<8, 2, true> : (shape == 2 ? sconv_f16x3_kernel<4, 2, true> : sconv_f16x3_kernel<4, 1, true>)))
+                              : (shape == 4 ? sconv_f16x3_kernel<6, 2, false> : (shape == 3 ? sconv_f16x3_kernel<8, 2, false> : (shape == 2 ? sconv_f16x3_kernel<4, 2, false> : sconv_f16x3_kernel<4, 1, false>)));
+    const int mr = shape == 4 ? 6 : (shape == 3 ? 8 : 4), lds = (shape == 1 ? 3 : 4) * (mr * 2 + 16) * 1024;      // DEPTH + 2 stages
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_strided_conv: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL(kfn, dim3((d.M / (32 * mr)) * nt), dim3(256), lds, st, a);
