@@ -257,6 +257,9 @@ struct OutArgs {
 #ifndef VQW_SCONV_192
 #define VQW_SCONV_192 1       // strided conv: 192-row blocks where they fill more CUs than 256-row blocks (tools/sconv_bench.py)
 #endif
+#ifndef VQW_X3_TAP_MINOR
+#define VQW_X3_TAP_MINOR 1      // K order of the conv main loop (0: taps outermost, as in round 1)
+#endif
 #ifndef VQW_X3_PAT_MEM
 #define VQW_X3_PAT_MEM 1      // issue pattern of the conv main loop: LDS / global-memory instructions per MFMA ...
 #define VQW_X3_PAT_ALU 2      // ... and address computations per MFMA (tools/x3_bench.py: 1/2 measured best)
@@ -331,7 +334,13 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem,
     }
     f32x4 rgA[NA + NBP], rgB[NA + NBP];
     auto rissue = [&](int s, f32x4 (&rg)[NA + NBP]) {
+#if VQW_X3_TAP_MINOR
+        // K order: channel chunk outermost, taps innermost -- the taps of one chunk read the same activation lines a few rows apart,
+        // in consecutive steps instead of Cin / 16 steps apart, while they are still in L2 (HBM reads of the gate conv d=8: 172 -> 104 MB)
+        const int ji = TAB ? s / spt : s % g.ks, kc = TAB ? (s - ji * spt) * 2 : (s / g.ks) * 2;
+#else
         const int ji = s / spt, kc = (s - ji * spt) * 2;
+#endif
         const int j = TAB ? g.tj0 + g.tjstep * ji : ji;
         const int e_ = TAB ? j - g.toff : 0;
         const int shift = TAB ? g.tsgn * (e_ >> 1) : (g.ks - 1 - j) * g.dilation * (g.dir < 0 ? -1 : 1);   // rows before / behind the batch row read as zero
