@@ -71,6 +71,9 @@ timeit('residual 1x1 (+planes)', lambda: K.f16x3_out_conv(xp=gp, wp=wres, net_in
                                                           w_scale_inv=1 / 256.0), 2.0 * N * R * R)
 timeit('gate backward', lambda: K.f16x3_out_conv(epi=1, xp=gr, Cin=S + R, xp_KC=(S + R) // 8, wp=wgb, aux0=th, aux1=sg, net_out=dpre2,
                                                  net_out_planes=dp, plane_scale=2.0 ** 20, B=B, T=T, R=R, S=0, w_scale_inv=2.0 ** -28), 2.0 * N * (S + R) * R)
+timeit('gate backward from gated / sigmoid', lambda: K.f16x3_out_conv(epi=1, xp=gr, Cin=S + R, xp_KC=(S + R) // 8, wp=wgb, aux0=out, aux1=sg, net_out=dpre2,
+                                                                      net_out_planes=dp, plane_scale=2.0 ** 20, B=B, T=T, R=R, S=0, w_scale_inv=2.0 ** -28,
+                                                                      aux0_is_gated=True), 2.0 * N * (S + R) * R)
 timeit('input gradient d=64', lambda: K.f16x3_out_conv(xp=dp, Cin=2 * R, ks=ks, dilation=64, direction=-1, wp=wdg, net_in=dnet, net_out=dnet2, B=B,
                                                        T=T, R=R, S=0, w_scale_inv=2.0 ** -28, net_out_planes=gr, planes_kc0=S // 8,
                                                        planes_KC=(S + R) // 8, plane_scale=2.0 ** 20), 2.0 * N * ks * 2 * R * R)

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void head_f16x3_kernel(const 
 // Gate backward (the transpose of gated_cnn's tanh * sigmoid, wavenet_ops.py:112-113, behind the transposed 1x1 convs):
 // dg = W_out^T [dskip; dnet] over the gradient planes (dskip in chunks 0..S/8-1, dnet behind it), then
 // dpre[filter c] = dg * sg * (1 - th^2), dpre[gate c] = dg * th * sg * (1 - sg); dpre also as planes for the input gradient.
-template <bool BF, int MR>
+template <bool BF, int MR, bool FG = false>      // FG: aux0 holds tanh * sigmoid instead of tanh
 __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
@@ -721,7 +721,6 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
     float gmax = 0.0f;
     bool gbad = false;
     const int PKC = d.planes_KC > 0 ? d.planes_KC : 2 * R / 8;
-    const bool from_gated = (d.flags & 2) != 0;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -738,19 +737,22 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { th[j][e] = pt[e * T + 32 * j]; sg[j][e] = pg[e * T + 32 * j]; }
-            if (from_gated) {       // aux0 holds tanh * sigmoid (the forward pass did not save tanh): tanh = gated / sigmoid, 0 where sigmoid underflowed
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) th[j][e] = sg[j][e] > 0.0f ? th[j][e] * __builtin_amdgcn_rcpf(sg[j][e]) : 0.0f;
-            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float dg = acc[i][j][v4 * 4 + e] * winv;
-                    qf[j][e] = dg * sg[j][e] * (1.0f - th[j][e] * th[j][e]);
-                    qg[j][e] = dg * th[j][e] * sg[j][e] * (1.0f - sg[j][e]);
+                    if constexpr (FG) {
+                        // th[][] holds g = tanh * sigmoid (the forward pass did not store tanh):
+                        //   sg (1 - tanh^2) = sg - g^2 / sg  (0 where the sigmoid underflowed),   tanh sg (1 - sg) = g (1 - sg)
+                        const float g_ = th[j][e], sv = sg[j][e];
+                        const float ff = sv > 0.0f ? sv - g_ * g_ * __builtin_amdgcn_rcpf(sv) : 0.0f;
+                        qf[j][e] = dg * ff;
+                        qg[j][e] = dg * g_ * (1.0f - sv);
+                    } else {
+                        qf[j][e] = dg * sg[j][e] * (1.0f - th[j][e] * th[j][e]);
+                        qg[j][e] = dg * th[j][e] * sg[j][e] * (1.0f - sg[j][e]);
+                    }
                     gmax = fmaxf(gmax, fmaxf(fabsf(qf[j][e]), fabsf(qg[j][e])));
                     gbad |= !(fabsf(dg) <= 3.0e38f);
                     pf[e * T + 32 * j] = qf[j][e];
@@ -1278,7 +1280,11 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
         return 0;
     }
     if (bwd) VQW_CHECK(d.S == 0 && d.R > 0 && d.aux0 && d.aux1 && d.Cin > 0, "vqw_f16x3_out_conv: gate backward needs S = 0, saved tanh (aux0) and sigmoid (aux1), Cin");
-    const kfn_t kfn = (bwd ? kbwds : kouts)[(bf ? 1 : 0) + (half ? 2 : 0)];
+    kfn_t kfn = (bwd ? kbwds : kouts)[(bf ? 1 : 0) + (half ? 2 : 0)];
+    if (bwd && (d.flags & 2)) {
+        VQW_CHECK(!bf, "vqw_f16x3_out_conv: gate backward from the gated output (flags bit 1) exists in the fp16x3 mode only");
+        kfn = half ? gate_bwd_f16x3_kernel<false, 4, true> : gate_bwd_f16x3_kernel<false, 8, true>;
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", lds);
     const int rows = bwd ? d.R : d.S + d.R;
