@@ -431,7 +431,7 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
  *   dgrad = 0: out[b][m][t] = bn_scale[m] * relu(sum_j sum_c w[j][c][m] x[b][c][2t + j - pad_left] + bias[m]) + bn_shift[m],
  *              t < T; xp = vqw_f16x3_split_activations(x [B][Cin][2T], mode | VQW_X3_S2D); save_r (or NULL) gets the relu output
  *   dgrad = 1: out[b][m][u] (u < 2T) = sum_{j, t: 2t + j - pad_left = u} sum_o wt[j][o][m] dy[b][o][t]; xp = plain planes of dy [B][Cin][T]
- * B * T % 256 == 0, Cin % 32 == 0, M % 128 == 0.  Results are scaled by w_scale_inv / (x_scale[0] * w_scale[0]).           */
+ * Cin % 32 == 0, M % 128 == 0 (B * T need not be a multiple of the 256-column tiles).  Results are scaled by w_scale_inv / (x_scale[0] * w_scale[0]).           */
 typedef struct vqw_f16x3_sconv_desc {
     const void* xp;
     const void* wp;

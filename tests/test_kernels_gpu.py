@@ -609,10 +609,10 @@ def test_wgrad_f16x3_stride2_matches_fp64(K, B, Tq, Tin, pl, scaled):
     assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item() + 2e-6 * tot0.abs().max().item()
 
 
-@pytest.mark.parametrize('B,Tout,Cin,M', [(2, 128, 128, 128), (1, 256, 128, 256), (8, 96, 128, 128), (8, 1664, 768, 768)])
+@pytest.mark.parametrize('B,Tout,Cin,M', [(2, 128, 128, 128), (1, 256, 128, 256), (8, 96, 128, 128), (3, 104, 128, 128), (8, 1664, 768, 768)])
 def test_strided_conv_f16x3_forward_and_input_gradient(K, B, Tout, Cin, M):
     """vqw_f16x3_strided_conv against torch's conv1d / its autograd in fp64 (encoder.py:17-18: k=5, stride 2, SAME = one zero in
-    front, two behind; bias -> relu -> BatchNorm affine): column tiles that straddle batch rows (T = 96, 1664), both paddings,
+    front, two behind; bias -> relu -> BatchNorm affine): column tiles that straddle batch rows (T = 96, 1664), a partial last column tile (3 x 104 = 312 columns), both paddings,
     operand scales on the device, the saved relu output; the last case is the benchmark's first 768 -> 768 layer (against the
     fp32 engine's kernels there)."""
     import torch.nn.functional as Fn

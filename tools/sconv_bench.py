@@ -27,7 +27,7 @@ def timeit(fn, n=20):
 
 def main():
     B, F, ks, pl = 8, 768, 5, 1
-    for Tout in (1664, 832, 416):
+    for Tout in (1664, 832, 416, 208, 104):
         Tin = 2 * Tout
         x = torch.randn(B, F, Tin, device=DEV)
         w = torch.randn(ks, F, F, device=DEV) * 0.02
@@ -54,10 +54,21 @@ def main():
         t32 = timeit(lambda: K.conv_gemm(x0=x, w=w, bias=bias, out0=out, save0=r, scale=bias, shift=bias, B=B, T_in=Tin, T_out=Tout, M=F, C0=F,
                                          in_stride=2, taps=[j - pl for j in range(ks)], out_relu=True))
         row.append('fp32 engine fwd %6.1f us' % t32)
+
+        def fp32_dgrad():
+            for p_ in (0, 1):
+                j0 = (p_ + pl) % 2
+                js = list(range(j0, ks, 2))
+                K.conv_gemm(x0=dy, w=wt[j0:], w_tap_stride=2 * F * F, out0=dx, B=B, T_in=Tout, T_out=(Tin - p_ + 1) // 2, M=F, C0=F,
+                            taps=[(p_ + pl - j) // 2 for j in js], out_tstride=2, out_toffset=p_, T_store=Tin)
+        row.append('dgrad %6.1f us' % timeit(fp32_dgrad))
         ts = timeit(lambda: K.f16x3_split_activations(x, xp, B, F, Tin, mode=K.X3_S2D))
         row.append('| s2d split %5.1f us' % ts)
         slab = torch.empty(256 * 65536, device=DEV)
         dw = torch.zeros(ks, F, F, device=DEV)
+        if Tout % 32:
+            print(' '.join(row), flush=True)
+            continue
         tw = timeit(lambda: K.f16x3_wgrad(p=x, q0=dy, dw=dw, slab=slab, B=B, T=Tout, Cp=F, Q0=F, taps=[j - pl for j in range(ks)], p_stride=2, T_p=Tin, mode=0))
         row.append('| wgrad %6.1f us' % tw)
         print(' '.join(row), flush=True)

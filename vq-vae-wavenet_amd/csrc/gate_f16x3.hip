@@ -795,9 +795,11 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
     const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
     const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
     int bcol[2], tcol[2];
+    bool cv[2];                      // the last column tile may reach past B * T (its operand rows read garbage or zero, nothing is stored)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + 64 * wv + 32 * j + l31;
+        cv[j] = n < a.NB;
         bcol[j] = n / T;
         tcol[j] = n - bcol[j] * T;
     }
@@ -837,8 +839,8 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const float y = fmaxf(acc[i][j][v4 * 4 + e] * winv + bq[e], rlo);
-                        if (sv) pr[j][ro] = y;
-                        po[j][ro] = sq[e] * y + hq[e];
+                        if (sv && cv[j]) pr[j][ro] = y;
+                        if (cv[j]) po[j][ro] = sq[e] * y + hq[e];
                     }
                 }
             }
@@ -860,7 +862,8 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) pd[j][(m0 + e) * (2 * T)] = acc[i][j][v4 * 4 + e] * winv;
+                        for (int j = 0; j < 2; ++j)
+                            if (cv[j]) pd[j][(m0 + e) * (2 * T)] = acc[i][j][v4 * 4 + e] * winv;
                 }
         }
     }
@@ -1334,7 +1337,7 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(dp, "vqw_f16x3_strided_conv: null descriptor");
     const vqw_f16x3_sconv_desc& d = *dp;
     VQW_CHECK(d.xp && d.wp && d.out, "vqw_f16x3_strided_conv: null operand");
-    VQW_CHECK(d.B > 0 && d.T > 0 && ((long)d.B * d.T) % 256 == 0, "vqw_f16x3_strided_conv: B * T must be a multiple of 256 (B=%d T=%d)", d.B, d.T);
+    VQW_CHECK(d.B > 0 && d.T > 0, "vqw_f16x3_strided_conv: bad shape (B=%d T=%d)", d.B, d.T);
     VQW_CHECK(d.Cin >= 64 && d.Cin % 32 == 0 && d.M > 0 && d.M % 128 == 0, "vqw_f16x3_strided_conv: Cin %% 32, M %% 128 (Cin=%d M=%d)", d.Cin, d.M);
     VQW_CHECK(d.ks >= 2 && d.ks <= 8 && d.pad_left >= 0 && d.pad_left < d.ks, "vqw_f16x3_strided_conv: 2..8 taps, 0 <= pad_left < ks (ks=%d pad_left=%d)", d.ks, d.pad_left);
     VQW_CHECK(!d.bn_scale || d.bn_shift, "vqw_f16x3_strided_conv: bn_scale needs bn_shift");
@@ -1349,7 +1352,7 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     //   forward  T=1664: 299 / 290 / 228 / 196   T=832: 154 / 129 / 196 / 155   T=416: 150 / 125 / 196 / 152
     //   dgrad    T=1664: 314 / 311 / 303 / 236   T=832: 198 / 142 / 275 / 184   T=416: 196 / 134 / 273 / 182
     // -> 256-row blocks for a launch that fills more than half of the chip with them, otherwise the deep 128-row shape
-    const int cus = vqw_device_cus(), nt = a.NB / 256;
+    const int cus = vqw_device_cus(), nt = (a.NB + 255) / 256;      // (a partial last column tile is masked in the epilogue)
     int shape = d.shape;
     if (shape == 0) shape = (d.M % 256 == 0 && (d.M / 256) * nt * 2 > cus) ? 3 : 2;
     // 192-row blocks where they fill more CUs than 256-row blocks without a second round (768 rows x 52 column tiles: 208 blocks

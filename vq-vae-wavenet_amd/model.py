@@ -342,11 +342,11 @@ class VQVAE:
             ws['X'] = [e(B, F, t) for t in ws['Tl']]      # BN outputs of encoder layers 0..5
             if self.x3_guard and not self.bf16 and F % 256 == 0:      # fp16x3 engine for layers 1..3 (_enc_x3_layers)
                 ws['eplanes'] = torch.empty(2 * B * F * ws['Tl'][0], dtype=torch.float16, device=dev)   # planes of one layer's operand
-                ws['ewp'] = torch.empty(3, 2 * 5 * F * F, dtype=torch.float16, device=dev)
-                ws['enc_amax'] = torch.zeros(8, dtype=torch.int32, device=dev)
-                ws['enc_scale'] = torch.ones(8, device=dev)
+                ws['ewp'] = torch.empty(5, 2 * 5 * F * F, dtype=torch.float16, device=dev)
+                ws['enc_amax'] = torch.zeros(12, dtype=torch.int32, device=dev)
+                ws['enc_scale'] = torch.ones(12, device=dev)
                 if train:
-                    ws['ewtp'] = torch.empty(3, 2 * 5 * F * F, dtype=torch.float16, device=dev)
+                    ws['ewtp'] = torch.empty(5, 2 * 5 * F * F, dtype=torch.float16, device=dev)
             if train:
                 ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
                 ws['y6'] = e(B, D, Tz)
@@ -435,9 +435,9 @@ class VQVAE:
         ex3 = ws['enc_x3'] = self._enc_x3_layers(ws)
         if ex3:
             ea, es, flag = ws['enc_amax'], ws['enc_scale'], self.x3_flag
-            K.f16x3_amax(P['enc_w'][:3], ea[0:1], flag=flag)
+            K.f16x3_amax(P['enc_w'], ea[0:1], flag=flag)
             K.f16x3_update_scales(ea[0:1], es[0:1], target_exp=14, flag=flag)
-            K.f16x3_pack_weights(P['enc_w'], ws['ewp'], 5 * F, F, F, 1.0, count=3, scale_dev=es[0:1], mode=0)
+            K.f16x3_pack_weights(P['enc_w'], ws['ewp'], 5 * F, F, F, 1.0, count=5, scale_dev=es[0:1], mode=0)
         for i in range(1, 6):
             Tout = ws['Tl'][i]
             pl, _ = same_pads(Tin, 5, 2)
@@ -467,14 +467,15 @@ class VQVAE:
         self._quantise(spk, ws)
 
     def _enc_x3_layers(self, ws):
-        """Encoder layers (1..3) whose conv and input gradient run on the fp16x3 engine this step: the guarded engine is active,
-        channel blocks of 128, whole 256-column tiles over the flat (batch, time) rows.  Slots of ws['enc_scale'] / ws['enc_amax']:
-        0 the kernels, i = 1..3 the input of layer i (X[i-1]), 3 + i the gradient of layer i's conv output."""
+        """Encoder layers (1..5) whose conv and input gradient run on the fp16x3 engine this step: the guarded engine is active,
+        channel blocks of 128 (the 256-column tiles over the flat (batch, time) rows may be partial: layers 4 and 5 have 1664 and
+        832 columns at B = 8).  Slots of ws['enc_scale'] / ws['enc_amax']: 0 the kernels, i = 1..5 the input of layer i (X[i-1]),
+        5 + i the gradient of layer i's conv output."""
         if not (self.x3_guard and self._x3_active and not self.bf16 and self.enc == '64' and self.F % 256 == 0
                 and os.environ.get('VQW_ENC_X3', '1') != '0' and 'ewtp' in ws):      # (training workspaces only: the step's
             return ()                                                                   #  range flag is read by train_step)
         B, Tl = ws['B'], ws['Tl']
-        return tuple(i for i in (1, 2, 3) if (B * Tl[i]) % 256 == 0 and Tl[i - 1] == 2 * Tl[i])
+        return tuple(i for i in (1, 2, 3, 4, 5) if B * Tl[i] >= 256 and Tl[i - 1] == 2 * Tl[i])
 
     def _side_stream(self):
         if self._side is None:
@@ -912,7 +913,7 @@ class VQVAE:
                and os.environ.get('VQW_ENC_WGRAD_X3', '1') != '0')
         ea, es, flag = ws.get('enc_amax'), ws.get('enc_scale'), self.x3_flag
         if ex3:
-            K.f16x3_pack_weights(Tt['enc_w'], ws['ewtp'], 5 * F, F, F, 1.0, count=3, scale_dev=es[0:1], mode=0)
+            K.f16x3_pack_weights(Tt['enc_w'], ws['ewtp'], 5 * F, F, F, 1.0, count=5, scale_dev=es[0:1], mode=0)
         for i in range(5, -1, -1):
             dX, r = ws['dX'][i], ws['r'][i]
             Ti = ws['Tl'][i]
@@ -924,8 +925,8 @@ class VQVAE:
                                dbeta=G['bn_beta'][i * F:(i + 1) * F],
                                dbias=None if on_w else G['enc_b'][i])   # dX := d(conv_i output); (the engine's wgrad sums the bias itself)
             if on_c or on_w:
-                K.f16x3_amax(dX, ea[3 + i:4 + i], flag=flag)
-                K.f16x3_update_scales(ea[3 + i:4 + i], es[3 + i:4 + i], target_exp=13, flag=flag)
+                K.f16x3_amax(dX, ea[5 + i:6 + i], flag=flag)
+                K.f16x3_update_scales(ea[5 + i:6 + i], es[5 + i:6 + i], target_exp=13, flag=flag)
                 if not on_c:                                         # (the forward pass measured X[i-1] otherwise)
                     K.f16x3_amax(ws['X'][i - 1], ea[i:i + 1], flag=flag)
                     K.f16x3_update_scales(ea[i:i + 1], es[i:i + 1], target_exp=13, flag=flag)
@@ -937,7 +938,7 @@ class VQVAE:
                     side.wait_event(ready)
                 if on_w:
                     K.f16x3_wgrad(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], slab=ws['wslab'], B=B, T=Ti, Cp=F, Q0=F,
-                                  taps=[j - pl for j in range(5)], p_scale=es[i:i + 1], q0_scale=es[3 + i:4 + i], p_stride=2, T_p=Tin,
+                                  taps=[j - pl for j in range(5)], p_scale=es[i:i + 1], q0_scale=es[5 + i:6 + i], p_stride=2, T_p=Tin,
                                   q_total=G['enc_b'][i], mode=0)
                 else:
                     if i == 0:
@@ -951,9 +952,9 @@ class VQVAE:
             if i == 0:
                 break
             if on_c:
-                K.f16x3_split_activations(dX, ws['eplanes'], B, F, Ti, scale_dev=es[3 + i:4 + i], mode=0)
+                K.f16x3_split_activations(dX, ws['eplanes'], B, F, Ti, scale_dev=es[5 + i:6 + i], mode=0)
                 K.f16x3_strided_conv(xp=ws['eplanes'], wp=ws['ewtp'][i - 1], out=ws['dX'][i - 1], B=B, T=Ti, Cin=F, M=F, ks=5,
-                                     pad_left=pl, dgrad=True, x_scale=es[3 + i:4 + i], w_scale=es[0:1])
+                                     pad_left=pl, dgrad=True, x_scale=es[5 + i:6 + i], w_scale=es[0:1])
                 continue
             # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
             nsplit = self._short_layer_split(F, (Tin + 1) // 2, B)
