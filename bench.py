@@ -380,8 +380,7 @@ def main():
             rec["dtype"] = ("f32 (storage and accumulation fp32; decoder contractions: each fp32 operand as two fp16 planes = 22 "
                             "significand bits, products h1h1 + h1h2 + h2h1 on the fp16 MFMA, device-side range guards -- forward, "
                             "input and weight gradients of the residual stack, of the 1x1 convs around it and of encoder layers "
-                            "1-5 (weight gradients: 1-3); the Cin=1 convs, encoder layer 6, the weight gradients of layers 4-5 and the "
-                            "condition projection on the fp32 MFMA / VALU)")
+                            "1-5; the Cin=1 convs, encoder layer 6 (1x1) and the condition projection on the fp32 MFMA / VALU)")
             rec["config"]["workload"] = rec["config"]["workload"].replace("fp32,", "fp32 (fp16x3 engine),")
             rec["roofline"].update({"kernel": "gate_f16x3_kernel<%d-row blocks> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; operands as two fp16 planes, 3 MFMA terms)" % (128 if model.x3_mode_fwd & 2 else 256),
                                     "achieved": 3 * ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * ach / PEAK_F16_MFMA_TFLOPS,

@@ -482,7 +482,8 @@ typedef struct vqw_f16x3_wgrad_desc {
     int32_t mode;           /* VQW_X3_* bits                                                                 */
     int32_t p_relu;         /* p := max(p, 0) on the way in                                                   */
     int32_t p_stride;       /* 0 / 1, or 2: p is the input of a stride-2 conv (encoder.py:17-18), row length Tp, read at
-                             * 2 t + tap_shift[j] (shifts of either sign; outside [0, Tp) = zero padding); fp16x3 mode only */
+                             * 2 t + tap_shift[j] (shifts of either sign; outside [0, Tp) = zero padding); fp16x3 mode only;
+                             * T then only has to be a multiple of 4                                           */
     int32_t Tp;
     int32_t xcd_group;      /* block placement: 0 = default (the taps of one tile and K range on one XCD where that fills the XCDs evenly), 1 = on, 2 = off */
 } vqw_f16x3_wgrad_desc;

@@ -564,7 +564,7 @@ def test_wgrad_f16x3_matches_fp64(K, B, T, d, Q1, scaled):
     assert float(got_seg[:, Q:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('B,Tq,Tin,pl,scaled', [(2, 416, 832, 1, True), (3, 32, 64, 1, False), (1, 128, 255, 2, True), (8, 1664, 3328, 1, True)])
+@pytest.mark.parametrize('B,Tq,Tin,pl,scaled', [(2, 416, 832, 1, True), (3, 32, 64, 1, False), (1, 128, 255, 2, True), (3, 104, 208, 1, True), (8, 1664, 3328, 1, True)])
 def test_wgrad_f16x3_stride2_matches_fp64(K, B, Tq, Tin, pl, scaled):
     """The encoder's strided convs (encoder.py:17-18, k=5 stride 2, SAME padding): dW[j][c][o] = sum p[b][c][2t + j - pl] q[b][o][t]
     with both paddings (2t + j - pl < 0 and >= T_in read zero), an odd input length, guard scales, the bias sum riding along;

@@ -966,14 +966,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         const int g = wv * 2 + (n >> 2), nn = n & 3;
         const int row = g * 32 + rsub;
         const int tq = pt0 + 8 * nn + 4 * hsel;
-        rgq[n] = vqw_buf_load4(rq, (int)((((size_t)pb * Qs + oq + row) * T + tq) * 4), 0);
+        // (S2: T need not be a multiple of the 32-step stage pairs -- steps behind the row's end read as zero)
+        rgq[n] = vqw_buf_load4(rq, (!S2 || tq < T) ? (int)((((size_t)pb * Qs + oq + row) * T + tq) * 4) : (int)0x80000000, 0);
         if (S2) {
             const size_t prow = ((size_t)pb * a.Cp + c0 + row) * a.Tp;
             f32x4 w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int idx = 2 * (tq + e) + shift;
-                w[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (idx >= 0 && idx < a.Tp) ? (int)((prow + idx) * 4) : (int)0x80000000, 0, 0));
+                w[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (idx >= 0 && idx < a.Tp && tq < T) ? (int)((prow + idx) * 4) : (int)0x80000000, 0, 0));
             }
             rgp[n] = w;
             return;
@@ -1376,7 +1377,8 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(dp, "vqw_f16x3_wgrad: null descriptor");
     const vqw_f16x3_wgrad_desc& d = *dp;
     VQW_CHECK(d.p && d.q0 && d.dw && d.slab, "vqw_f16x3_wgrad: null operand");
-    VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 32 == 0, "vqw_f16x3_wgrad: T must be a positive multiple of 32 (got %d)", d.T);
+    VQW_CHECK(d.B > 0 && d.T > 0 && (d.T % 32 == 0 || (d.p_stride == 2 && d.T % 4 == 0)),
+              "vqw_f16x3_wgrad: T must be a positive multiple of 32 (of 4 with p_stride 2) (got %d)", d.T);
     VQW_CHECK(d.Cp > 0 && d.Cp % 256 == 0 && d.Q0 > 0 && d.Q0 % 256 == 0 && d.Q1 >= 0 && d.Q1 % 256 == 0 && (d.Q1 == 0 || d.q1),
               "vqw_f16x3_wgrad: Cp, Q0, Q1 must be multiples of 256 (Cp=%d Q0=%d Q1=%d)", d.Cp, d.Q0, d.Q1);
     VQW_CHECK(d.ntaps >= 1 && d.ntaps <= VQW_MAX_TAPS, "vqw_f16x3_wgrad: 1..%d taps", VQW_MAX_TAPS);
@@ -1396,7 +1398,7 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
     a.p = d.p; a.q0 = d.q0; a.q1 = d.q1; a.slab = d.slab; a.sp = d.p_scale; a.sq0 = d.q0_scale; a.sq1 = d.q1_scale;
     a.B = d.B; a.T = d.T; a.Cp = d.Cp; a.Q0 = d.Q0; a.Q1 = d.Q1; a.ntaps = d.ntaps; a.Tp = Tp; a.p_relu = d.p_relu;
     for (int j = 0; j < d.ntaps; ++j) a.shift[j] = d.tap_shift[j];
-    a.pairs_row = d.T / 32; a.pairs_total = d.B * a.pairs_row;
+    a.pairs_row = (d.T + 31) / 32; a.pairs_total = d.B * a.pairs_row;
     a.n_nt = (d.Q0 + d.Q1) / 256;
     const int tiles = d.ntaps * (d.Cp / 256) * a.n_nt;
     int nsplit = d.nsplit > 0 ? d.nsplit : vqw_device_cus() / tiles;     // one round of blocks

@@ -920,7 +920,7 @@ class VQVAE:
             Tin = ws['Tl'][i - 1] if i > 0 else T
             pl, _ = same_pads(Tin, 5, 2)
             on_c = i in ex3
-            on_w = wg3 and 1 <= i <= 3 and Ti % 32 == 0 and Tin == 2 * Ti and B * F * Tin * 4 < (1 << 31)
+            on_w = wg3 and 1 <= i <= 5 and Ti % 4 == 0 and B * Ti >= 256 and Tin == 2 * Ti and B * F * Tin * 4 < (1 << 31)
             K.bn_relu_bwd_sums(dX, r, r, sc[i * F:(i + 1) * F], dX, dscale=dsc[i * F:(i + 1) * F],
                                dbeta=G['bn_beta'][i * F:(i + 1) * F],
                                dbias=None if on_w else G['enc_b'][i])   # dX := d(conv_i output); (the engine's wgrad sums the bias itself)
