@@ -905,7 +905,7 @@ class VQVAE:
         K.conv_gemm(x0=dz, w=Tt['enc_w6'], out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
-        # layers 1..3 on the fp16x3 engine: the input gradient where the forward conv ran there (ws['enc_x3']), the weight
+        # layers 1..5 on the fp16x3 engine: the input gradient where the forward conv ran there (ws['enc_x3']), the weight
         # gradient (operands split in registers, bias sums riding along) whenever the decoder's ran there this step.  Scales:
         # exact powers of two from max-abs passes over THIS step's tensors (slots: _enc_x3_layers)
         ex3 = ws.get('enc_x3', ())
