@@ -61,51 +61,72 @@ def default_configs():
     return m, w
 
 
-class GateConvTimer:
-    """HIP events around every launch of the dominant kernel, on the launch stream."""
+class KernelTimers:
+    """HIP events around every launch of the kernel families on the roofline lines, recorded on the stream the launch goes
+    to (the weight gradients run on the model's side stream: torch.cuda.Event.record() uses the stream that is current
+    at the call, which is that one).  'gate': the dilated gate conv (fp32 engine: conv_gemm with the GATE epilogue).
+    'wgrad': every engine weight-gradient launch, with its ALGORITHMIC flop count 2 * B * T * Cp * taps * (Q0 + Q1)."""
 
     def __init__(self, kernels_mod):
         self.K = kernels_mod
-        self.orig = kernels_mod.conv_gemm
-        self.orig_x3 = kernels_mod.f16x3_gate_conv
-        self.x3 = False          # the fp16x3 gate kernel was the one launched
-        self.events = []
+        self.orig = {n: getattr(kernels_mod, n) for n in ('conv_gemm', 'f16x3_gate_conv', 'f16x3_wgrad', 'wgrad_gemm')}
+        self.x3 = False          # the plane engine's gate kernel was the one launched
+        self.events = {'gate': [], 'wgrad': []}
         self.on = False
 
-    def __enter__(self):
-        K = self.K
+    def _timed(self, family, fn, kw, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(**kw)
+        e1.record()
+        self.events[family].append((e0, e1, flops))
 
-        def wrapped(**kw):
+    def __enter__(self):
+        K, o = self.K, self.orig
+
+        def conv_gemm(**kw):
             if self.on and kw.get('epilogue') == K.EPI_GATE:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                self.orig(**kw)
-                e1.record()
-                self.events.append((e0, e1))
+                self._timed('gate', o['conv_gemm'], kw, 0.0)
             else:
-                self.orig(**kw)
-        def wrapped_x3(**kw):
+                o['conv_gemm'](**kw)
+
+        def gate_conv(**kw):
             if self.on:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                self.orig_x3(**kw)
-                e1.record()
-                self.events.append((e0, e1))
+                self._timed('gate', o['f16x3_gate_conv'], kw, 0.0)
                 self.x3 = True
             else:
-                self.orig_x3(**kw)
-        K.conv_gemm = wrapped
-        K.f16x3_gate_conv = wrapped_x3
+                o['f16x3_gate_conv'](**kw)
+
+        def wgrad_x3(**kw):
+            if self.on:
+                self._timed('wgrad', o['f16x3_wgrad'], kw, 2.0 * kw['B'] * kw['T'] * kw['Cp'] * len(kw['taps']) * (kw['Q0'] + kw.get('Q1', 0)))
+            else:
+                o['f16x3_wgrad'](**kw)
+
+        def wgrad_fp32(**kw):
+            if self.on:
+                self._timed('wgrad', o['wgrad_gemm'], kw, 2.0 * kw['B'] * kw['T_q'] * kw['Cp'] * len(kw['taps']) * (kw['Q0'] + kw.get('Q1', 0)))
+            else:
+                o['wgrad_gemm'](**kw)
+        K.conv_gemm, K.f16x3_gate_conv, K.f16x3_wgrad, K.wgrad_gemm = conv_gemm, gate_conv, wgrad_x3, wgrad_fp32
         return self
 
     def __exit__(self, *a):
-        self.K.conv_gemm = self.orig
-        self.K.f16x3_gate_conv = self.orig_x3
+        for n, f in self.orig.items():
+            setattr(self.K, n, f)
 
-    def mean_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
+    def reset(self):
+        self.events = {'gate': [], 'wgrad': []}
+
+    def mean_ms(self, family='gate'):
+        ev = self.events[family]
+        return sum(a.elapsed_time(b) for a, b, _ in ev) / max(len(ev), 1)
+
+    def family(self, family):
+        """(launches, total ms, total algorithmic flop) of one family over the recorded region."""
+        ev = self.events[family]
+        return len(ev), sum(a.elapsed_time(b) for a, b, _ in ev), sum(f for _, _, f in ev)
 
 
 def hbm_traffic(name='round1_gate_conv_traffic.json'):
@@ -204,6 +225,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen', action='store_true')
     ap.add_argument('--no-other-engine', action='store_true', help='skip the extra timing of the same step on the fp32-MFMA engine')
+    ap.add_argument('--no-config4', action='store_true', help="skip the 5-step '2019' encoder / bf16 leg (BASELINE.json configs[4])")
     ap.add_argument('--probe-ranks', action='store_true', help='only start the ranks and report how many joined (no GPU work)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 code path)")
     a = ap.parse_args()
@@ -266,7 +288,7 @@ def main():
         torch.cuda.synchronize()
 
     log('model built, %d parameters; warm-up' % model.n_flat)
-    with GateConvTimer(K) as gt:
+    with KernelTimers(K) as gt:
         for _ in range(a.warmup):
             model.train_step(x, spk)
         barrier()
@@ -278,8 +300,25 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         gt.on = False
-        gate_ms = gt.mean_ms()
+        gate_ms = gt.mean_ms('gate')
         gate_x3 = gt.x3
+        wg_n, wg_ms, wg_flop = gt.family('wgrad')
+        # the same kernel families once more with the step on ONE stream (outside the timed region): in the timed region the
+        # weight gradients share the chip with the backward chain's kernels, so their event brackets include the other
+        # stream's work; these are the stand-alone durations profiles/*_single_stream.csv shows
+        ss = None
+        if world == 1 and model.overlap_wgrad:
+            gt.reset()
+            model.overlap_wgrad = False
+            model.train_step(x, spk)
+            torch.cuda.synchronize()
+            gt.on = True
+            for _ in range(3):
+                model.train_step(x, spk)
+            torch.cuda.synchronize()
+            gt.on = False
+            model.overlap_wgrad = True
+            ss = {'gate_ms': gt.mean_ms('gate'), 'wgrad': gt.family('wgrad')}
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -349,10 +388,52 @@ def main():
                                                "us_per_step": g8dt / a.gen_steps * 1e6}
             log('generation, %d utterances on one GPU: %.1f us/step' % (B, g8dt / a.gen_steps * 1e6))
 
+    # BASELINE.json configs[4] on this GPU: '2019' encoder, T=6400, bf16 storage + fp32 accumulate, 5 timed steps
+    cfg4 = None
+    if world == 1 and not a.no_config4 and a.dtype == 'f32' and (a.encoder or m['encoder']) == '64':
+        model.free_workspaces()
+        ws = None
+        torch.cuda.empty_cache()
+        try:
+            os.environ['VQW_DTYPE'] = 'bf16'
+            try:
+                m4 = dict(m, encoder='2019')
+                model4 = pkg.model.VQVAE(m4, w, S, device=dev, seed=0)
+            finally:
+                del os.environ['VQW_DTYPE']
+            T4 = 6400
+            x4, spk4 = synthetic_batch(B, T4, S, 1234, dev)
+            for _ in range(3):
+                model4.train_step(x4, spk4)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(5):
+                ws4 = model4.train_step(x4, spk4)
+            torch.cuda.synchronize()
+            d4 = (time.perf_counter() - t4) / 5
+            cfg4 = {"workload": "LibriSpeech '2019' encoder, K=512, len=%d batch=%d, bf16 storage + fp32 accumulate, full train step" % (T4, B),
+                    "value": B * T4 / d4, "unit": "audio-samples/s", "ms_per_step": d4 * 1e3, "steps": 5, "warmup": 3,
+                    "dtype": "bf16 planes (v_mfma_f32_32x32x16_bf16), fp32 accumulate / master weights / optimiser",
+                    "steps_on_engine": model4.x3_steps, "loss": model4.losses(ws4)[0]}
+            log('configs[4] bf16: %.2f ms/step' % (d4 * 1e3))
+            del model4, ws4
+            torch.cuda.empty_cache()
+        except Exception as e:
+            cfg4 = {"error": '%s: %s' % (type(e).__name__, e)}
+            log('configs[4] leg failed: %s' % cfg4['error'])
+
     if rank == 0:
         R, ks = model.R, model.ks
-        flops_gate = 2.0 * B * T * (ks * R) * (2 * R)       # K1: causal dilated conv 256 -> 512, k=3
+        flops_gate = 2.0 * B * T * (ks * R) * (2 * R)       # K1: causal dilated conv 256 -> 512, k=3 (ALGORITHMIC: SURVEY 8(d))
         ach = flops_gate / (gate_ms * 1e-3) / 1e12
+        step_tflops = 118.14e6 * B * T * a.steps / dt / 1e12   # 118.14 MFLOP per audio sample, fwd + bwd
+
+        def wgrad_line(n, ms, flop, peak, note):
+            if not n or ms <= 0:
+                return None
+            ach_w = flop / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": note, "achieved": ach_w, "peak": peak, "unit": "TFLOP/s", "frac": ach_w / peak,
+                    "launches_per_step": n / a.steps, "ms_per_step": ms / a.steps, "flop_per_step": flop / a.steps, "traffic": None}
         rec = {
             "metric": "training audio-samples/sec", "value": B * T * a.steps * world / dt,
             "unit": "audio-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -366,28 +447,48 @@ def main():
                          "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": hbm_traffic(),
                          "ms_per_launch": gate_ms, "flop_per_launch": flops_gate,
-                         "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_FP32_MFMA_TFLOPS * 1e12)},
+                         "whole_step_tflops": step_tflops, "whole_step_frac": step_tflops / PEAK_FP32_MFMA_TFLOPS},
         }
+        rec["roofline_wgrad"] = wgrad_line(wg_n, wg_ms, wg_flop, PEAK_FP32_MFMA_TFLOPS, "wgrad_kernel<2,2> (fp32 MFMA, atomics)")
         if gate_x3 and model.bf16:   # BASELINE.json configs[4]: one bf16 MFMA per product
             rec["dtype"] = ("bf16 (decoder contraction operands stored as bf16 planes, v_mfma_f32_32x32x16_bf16, fp32 accumulate; master "
                             "weights, optimiser, residual stream, encoder, VQ and losses fp32)")
             rec["config"]["workload"] = rec["config"]["workload"].replace("fp32,", "bf16 storage + fp32 accumulate,")
             rec["roofline"].update({"kernel": "gate_f16x3_kernel<bf16> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; one bf16 plane per operand)",
                                     "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                                    "whole_step_frac": (118.14e6 * B * T * a.steps / dt) / (PEAK_F16_MFMA_TFLOPS * 1e12)})
+                                    "whole_step_frac": step_tflops / PEAK_F16_MFMA_TFLOPS})
+            rec["roofline_wgrad"] = wgrad_line(wg_n, wg_ms, wg_flop, PEAK_F16_MFMA_TFLOPS, "wgrad_f16x3_kernel<bf16> + fp32-engine launches")
             rec["engine"] = {"name": "bf16", "steps_on_engine": model.x3_steps}
-        elif gate_x3:   # the fp16x3 engine ran: three fp16 MFMA terms per product, priced on the 16-bit pipe
-            rec["dtype"] = ("f32 (storage and accumulation fp32; decoder contractions: each fp32 operand as two fp16 planes = 22 "
-                            "significand bits, products h1h1 + h1h2 + h2h1 on the fp16 MFMA, device-side range guards -- forward, "
-                            "input and weight gradients of the residual stack, of the 1x1 convs around it and of encoder layers "
-                            "1-5; the Cin=1 convs, encoder layer 6 (1x1) and the condition projection on the fp32 MFMA / VALU)")
+        elif gate_x3:
+            # the fp16x3 engine ran.  frac = ALGORITHMIC flop / time / the peak of the pipe the kernel runs on (the
+            # fp16 MFMA); the engine issues three fp16 MFMA terms per algorithmic product, so the pipe's issue rate is 3x that:
+            # reported separately as pipe_utilisation, never as achieved work
+            rec["dtype"] = ("f32 via fp16x3 (storage and accumulation fp32; the engine's contraction operands are each fp32 value split "
+                            "into two fp16 planes = 22-23 significand bits, products h1h1 + h1h2 + h2h1 on the fp16 MFMA, device-side "
+                            "range guards -- forward, input and weight gradients of the residual stack, of the 1x1 convs around it and "
+                            "of encoder layers 1-5; the Cin=1 convs, encoder layer 6 (1x1) and the condition projection on the fp32 "
+                            "MFMA / VALU; the exact-fp32 engine's number for the same step is engine_fp32)")
             rec["config"]["workload"] = rec["config"]["workload"].replace("fp32,", "fp32 (fp16x3 engine),")
             rec["roofline"].update({"kernel": "gate_f16x3_kernel<%d-row blocks> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; operands as two fp16 planes, 3 MFMA terms)" % (128 if model.x3_mode_fwd & 2 else 256),
-                                    "achieved": 3 * ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": 3 * ach / PEAK_F16_MFMA_TFLOPS,
-                                    "fp32_equivalent_tflops": ach, "flop_per_launch": 3 * flops_gate, "traffic": hbm_traffic('round2_gate_f16x3_traffic.json' if model.x3_mode_fwd & 2 else 'round2_gate_f16x3_traffic_256row_blocks.json'),
-                                    "whole_step_frac": None,
-                                    "whole_step_fp32_equivalent_tflops": 118.14e6 * B * T * a.steps / dt / 1e12})
+                                    "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": ach / PEAK_F16_MFMA_TFLOPS,
+                                    "pipe_utilisation": 3 * ach / PEAK_F16_MFMA_TFLOPS, "mfma_terms_per_product": 3,
+                                    "traffic": hbm_traffic('round2_gate_f16x3_traffic.json' if model.x3_mode_fwd & 2 else 'round2_gate_f16x3_traffic_256row_blocks.json'),
+                                    "whole_step_frac": step_tflops / PEAK_F16_MFMA_TFLOPS})
+            rec["roofline_wgrad"] = wgrad_line(wg_n, wg_ms, wg_flop, PEAK_F16_MFMA_TFLOPS,
+                                               "wgrad_f16x3_kernel (all engine weight-gradient launches of the step: decoder, convs around the stack, "
+                                               "encoder layers 1-5; slab reduction inside the kernel) + the 2 fp32-engine launches")
+            if rec["roofline_wgrad"]:
+                rec["roofline_wgrad"]["pipe_utilisation"] = 3 * rec["roofline_wgrad"]["frac"]
             rec["engine"] = {"name": "f16x3", "steps_on_engine": model.x3_steps, "steps_repeated_on_fp32": model.x3_fallbacks}
+        if ss:      # single-stream durations of the same families (3 extra steps after the timed region)
+            n1, ms1, fl1 = ss['wgrad']
+            pk = rec["roofline"]["peak"]
+            rec["roofline"]["single_stream"] = {"ms_per_launch": ss['gate_ms'], "frac": flops_gate / (ss['gate_ms'] * 1e-3) / 1e12 / pk}
+            if rec["roofline_wgrad"] and n1:
+                rec["roofline_wgrad"]["single_stream"] = {"ms_per_step": ms1 / 3, "achieved": fl1 / (ms1 * 1e-3) / 1e12,
+                                                          "frac": fl1 / (ms1 * 1e-3) / 1e12 / pk}
+        if cfg4:
+            rec["config4_bf16"] = cfg4
         if exp:
             rec["engine_fp32"] = exp
         if gen:

@@ -236,6 +236,13 @@ int vqw_speaker_tile_bwd(const float* dcond, int64_t dcond_bstride, int row0,
 int vqw_softmax_xent(const float* logits, const int32_t* labels, float* dlogits,
                      float* probs, float* loss_sum, float grad_scale, int B, int Q, int T,
                      vqw_stream_t s);
+/* The same op as the two entries SURVEY 8(b) names (tf.nn.sparse_softmax_cross_entropy_with_logits and its gradient,
+ * model.py:91-94): _fwd adds the CE sum into loss_sum[0] (probs optional); _bwd writes (softmax - onehot) * grad_scale,
+ * recomputed from the logits (dlogits may alias logits).                                */
+int vqw_softmax_xent_fwd(const float* logits, const int32_t* labels, float* probs, float* loss_sum,
+                         int B, int Q, int T, vqw_stream_t s);
+int vqw_softmax_xent_bwd(const float* logits, const int32_t* labels, float* dlogits, float grad_scale,
+                         int B, int Q, int T, vqw_stream_t s);
 
 /* ------------------------------------------------------------------------------------
  * Fused TF-1.x Adam + ExponentialMovingAverage step over a flat buffer --

@@ -142,12 +142,14 @@ def is_trainable(name):
 # ----------------------------------------------------------------------------
 # Forward graph
 # ----------------------------------------------------------------------------
-def encoder_64(x, P):
-    """encoder.py:13-26.  x [B,T,1] -> z_e [B,T/64,D]."""
+def encoder_64(x, P, collect=None):
+    """encoder.py:13-26.  x [B,T,1] -> z_e [B,T/64,D].  collect: the relu outputs of the six layers ('enc_relu_<i>')."""
     net = x
     for i in range(6):
         net = R.keras_conv1d(net, P[conv_scope(i) + '/kernel'], P[conv_scope(i) + '/bias'],
                              stride=2, padding='same', relu=True)
+        if collect is not None:
+            collect['enc_relu_%d' % i] = net
         b = bn_scope(i)
         net = R.batch_norm_inference(net, P[b + '/gamma'], P[b + '/beta'],
                                      P[b + '/moving_mean'], P[b + '/moving_variance'])
@@ -210,8 +212,9 @@ def discretise(z_e, emb):
     return q, e_k, z_q
 
 
-def wavenet_build(x, local_condition, P, wcfg, collect=None):
-    """wavenet.py:24-100.  x [B,T,1] raw audio; -> logits [B*T,256], labels int32 [B*T]."""
+def wavenet_build(x, local_condition, P, wcfg, collect=None, global_condition=None):
+    """wavenet.py:24-100.  x [B,T,1] raw audio; -> logits [B*T,256], labels int32 [B*T].  global_condition [B,Tg,Cg]: the
+    second add_condition of wavenet_ops.py:109-110 and wavenet.py:89-91 (None in the reference's own decoder.py:34-36)."""
     labels = R.mu_law_encode(x, to_int=True).reshape(-1)
     inputs = R.mu_law_encode(R.shift_right(x))
     net = R.conv1d_v2(inputs, P['decoder/preprocess/kernel'], P['decoder/preprocess/bias'])
@@ -224,7 +227,7 @@ def wavenet_build(x, local_condition, P, wcfg, collect=None):
     for i, d in enumerate(wcfg["dilation_rates"]):
         s = layer_scope(i, wcfg["num_cycle_layers"])
         p = {k[len(s) + 1:]: v for k, v in P.items() if k.startswith(s + '/')}
-        skip_out, res_out = R.residual_stack(net, p, Df, d, local_condition)
+        skip_out, res_out = R.residual_stack(net, p, Df, d, local_condition, global_condition)
         skip = skip + skip_out
         net = net + res_out
         if collect is not None:
@@ -232,6 +235,9 @@ def wavenet_build(x, local_condition, P, wcfg, collect=None):
     net = torch.relu(skip)
     net = R.conv1d_v2(net, P['decoder/postprocess1/kernel'], P['decoder/postprocess1/bias'])
     net = R.add_condition(net, local_condition, P['decoder/postprocess1/local_condition/kernel'])
+    net = R.add_condition(net, global_condition, P.get('decoder/postprocess1/global_condition/kernel'))
+    if collect is not None:
+        collect['post1_pre'] = net
     net = torch.relu(net)
     net = R.conv1d_v2(net, P['decoder/postprocess2/kernel'], P['decoder/postprocess2/bias'])
     if collect is not None:
@@ -241,7 +247,8 @@ def wavenet_build(x, local_condition, P, wcfg, collect=None):
 
 def forward(x, speaker_idx, P, mcfg, wcfg, collect=None):
     """model.py:145-151 (build) up to the losses.  x [B,T,1], speaker_idx int64 [B]."""
-    z_e = {"Magenta": encoder_magenta, "2019": encoder_2019, "64": encoder_64}[mcfg.get("encoder", "64")](x, P)  # model.py:36
+    enc = mcfg.get("encoder", "64")
+    z_e = encoder_64(x, P, collect) if enc == "64" else {"Magenta": encoder_magenta, "2019": encoder_2019}[enc](x, P)  # model.py:36
     if mcfg["use_vq"]:
         q, e_k, z_q = discretise(z_e, P['embedding/embedding'])         # model.py:57-74
     else:
@@ -295,12 +302,13 @@ def adam_ema_step(P, grads, state, lr, beta1=0.9, beta2=0.999, eps=1e-8, decay=0
             e.sub_((1 - decay) * (e - P[n]))
 
 
-def train_step(x, speaker_idx, P, mcfg, wcfg, state, step):
-    """One sess.run(train_op) (train.py:104-114): returns losses + grads (for tests)."""
+def train_step(x, speaker_idx, P, mcfg, wcfg, state, step, collect=None):
+    """One sess.run(train_op) (train.py:104-114): returns losses + grads (for tests).  collect: dict that receives the
+    forward pass's intermediate tensors (the inputs of the relus among them: 'skip_sum', 'post1_pre', 'enc_relu_<i>')."""
     for n, p in P.items():
         p.requires_grad_(is_trainable(n))
         p.grad = None
-    out = forward(x, speaker_idx, P, mcfg, wcfg)
+    out = forward(x, speaker_idx, P, mcfg, wcfg, collect)
     out['loss'].backward()
     grads = {n: p.grad.detach().clone() for n, p in P.items() if p.grad is not None}
     for p in P.values():
@@ -325,8 +333,9 @@ class FastGenerator:
         self.layers = [R.FastConvState(w["kernel_size"], d, self.B, w["residual_filters"])
                        for d in w["dilation_rates"]]
 
-    def step(self, input_t, cond_t):
-        """input_t [B,1] in [-1,1]; cond_t [B,Cc] -> probabilities [B,256]."""
+    def step(self, input_t, cond_t, global_t=None):
+        """input_t [B,1] in [-1,1]; cond_t [B,Cc] -> probabilities [B,256].  global_t [B,Cg]: fast_condition under the scope
+        'global_condition' (wavenet_ops.py:232-233, wavenet.py:160-162)."""
         P, w = self.P, self.w
         x = R.mu_law_encode(input_t)                                     # wavenet.py:113
         current = self.pre.step(x, P['decoder/preprocess/kernel'], P['decoder/preprocess/bias'])
@@ -336,12 +345,16 @@ class FastGenerator:
             s = layer_scope(i, w["num_cycle_layers"])
             net = self.layers[i].step(current, P[s + '/gated/kernel'], P[s + '/gated/bias'])
             net = net + R.linear(cond_t, P[s + '/gated/local_condition/kernel'])
+            if global_t is not None:
+                net = net + R.linear(global_t, P[s + '/gated/global_condition/kernel'])
             gated = torch.tanh(net[:, :Df]) * torch.sigmoid(net[:, Df:])
             skip = skip + R.linear(gated, P[s + '/skip/kernel'], P[s + '/skip/bias'])
             current = current + R.linear(gated, P[s + '/residual/kernel'], P[s + '/residual/bias'])
         net = torch.relu(skip)
         net = R.linear(net, P['decoder/postprocess1/kernel'], P['decoder/postprocess1/bias'])
         net = net + R.linear(cond_t, P['decoder/postprocess1/local_condition/kernel'])
+        if global_t is not None:
+            net = net + R.linear(global_t, P['decoder/postprocess1/global_condition/kernel'])
         net = torch.relu(net)
         net = R.linear(net, P['decoder/postprocess2/kernel'], P['decoder/postprocess2/bias'])
         return torch.softmax(net, dim=-1)

@@ -90,17 +90,18 @@ def add_condition(net, condition, cond_kernel):
     return net.reshape(B, net_len, out_channels)
 
 
-def gated_cnn(net, p, dilation_filters, dilations, local_condition):
-    """wavenet_ops.py:104-114.  p: dict with gated/{kernel,bias,local_condition/kernel}."""
+def gated_cnn(net, p, dilation_filters, dilations, local_condition, global_condition=None):
+    """wavenet_ops.py:104-114.  p: dict with gated/{kernel,bias,local_condition/kernel[,global_condition/kernel]}."""
     net = conv1d_v2(net, p['gated/kernel'], p['gated/bias'], dilations)
     net = add_condition(net, local_condition, p.get('gated/local_condition/kernel'))
+    net = add_condition(net, global_condition, p.get('gated/global_condition/kernel'))      # :109-110
     net_filter, net_gate = net[:, :, :dilation_filters], net[:, :, dilation_filters:]
     return torch.tanh(net_filter) * torch.sigmoid(net_gate)
 
 
-def residual_stack(net, p, dilation_filters, dilations, local_condition):
+def residual_stack(net, p, dilation_filters, dilations, local_condition, global_condition=None):
     """wavenet_ops.py:117-138 -> (skip_connection, residual_connection)."""
-    gated = gated_cnn(net, p, dilation_filters, dilations, local_condition)
+    gated = gated_cnn(net, p, dilation_filters, dilations, local_condition, global_condition)
     skip = conv1d_v2(gated, p['skip/kernel'], p['skip/bias'])
     res = conv1d_v2(gated, p['residual/kernel'], p['residual/bias'])
     return skip, res

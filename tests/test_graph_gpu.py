@@ -88,3 +88,57 @@ def test_fast_ops_one_sample_at_a_time(pkg):
         with G.variable_scope('decoder'):
             got = wn.build_generator(torch.zeros(2, 1).cuda(), enc[:, 0].cuda(), None, 2)
         np.testing.assert_allclose(got.cpu().numpy(), pr, rtol=2e-4, atol=1e-6)
+
+
+def test_global_condition_is_a_second_add_condition(pkg):
+    """wavenet_ops.py:109-110,232-233 and wavenet.py:89-91,160-162: a non-None global_condition ([B, 1, Cg], e.g. a speaker
+    embedding that is NOT concatenated) is projected by its own 1x1 under the scope 'global_condition' and added like the local
+    one.  The reference's decoder never does this (decoder.py:34-36 concatenates and passes None), but the op surface has it:
+    training graph and per-sample graph against the oracle, and the variables the graph creates."""
+    G = pkg.graph
+    m, w = tiny_cfg()
+    P = M.init_params(m, w, 10, seed=13, randomize_all=True)
+    g = torch.Generator().manual_seed(5)
+    Cg, R2, S = 24, 2 * w['dilation_filters'], w['skip_filters']
+    ncl = w['num_cycle_layers']
+    for i in range(len(w['dilation_rates'])):
+        P[M.layer_scope(i, ncl) + '/gated/global_condition/kernel'] = (torch.rand(1, Cg, R2, generator=g) - 0.5) * 0.3
+    P['decoder/postprocess1/global_condition/kernel'] = (torch.rand(1, Cg, S, generator=g) - 0.5) * 0.3
+    x, spk, _ = M.synthetic_batch(2, 512, 10, 1234)
+    glob = torch.randn(2, 1, Cg, generator=g)
+    with torch.no_grad():
+        local = M.forward(x, spk, P, m, w)['local_condition']
+        want, labels = M.wavenet_build(x, local, P, w, global_condition=glob)
+        base, _ = M.wavenet_build(x, local, P, w)
+    assert relerr(want, base) > 1e-2                                       # the second condition matters in this set-up
+    store = G.VariableStore({k: v.clone() for k, v in P.items()}, device='cuda')
+    wn = G.Wavenet(w)
+    with store.use(), G.variable_scope('decoder'):
+        logits, lab = wn.build(x.cuda(), local.cuda(), glob.cuda())
+    assert torch.equal(lab.cpu(), labels) and relerr(logits, want) < 2e-4
+    assert set(store.vars) == set(P)
+    # a global condition with its own frame rate: Tg = 4 frames against Tz = 8 (the epilogue operand is their sum at 8)
+    glob4 = torch.randn(2, 4, Cg, generator=g)
+    with torch.no_grad():
+        want4, _ = M.wavenet_build(x, local, P, w, global_condition=glob4)
+    with store.use(), G.variable_scope('decoder'):
+        logits4, _ = wn.build(x.cuda(), local.cuda(), glob4.cuda())
+    assert relerr(logits4, want4) < 2e-4
+    # implicit creation: names and shapes
+    fresh = G.VariableStore(device='cuda', seed=2)
+    with fresh.use(), G.variable_scope('decoder'):
+        G.Wavenet(w).build(x.cuda(), local.cuda(), glob.cuda())
+    assert {k: tuple(v.shape) for k, v in fresh.vars.items()} == {k: tuple(v.shape) for k, v in P.items() if k.startswith('decoder/')}
+    # per-sample graph
+    ref = M.FastGenerator(P, w, 2)
+    a = np.zeros([2, 1], np.float32)
+    with store.use(), torch.no_grad():
+        for i in range(12):
+            cond = local[:, i // 64]
+            pr = ref.step(torch.from_numpy(a), cond, glob[:, 0]).numpy()
+            with G.variable_scope('decoder'):
+                got = wn.build_generator(torch.from_numpy(a).cuda(), cond.cuda(), glob[:, 0].cuda(), 2)
+            for op in wn.push_ops:
+                op()
+            np.testing.assert_allclose(got.cpu().numpy(), pr, rtol=2e-4, atol=1e-6)
+            a = M.R.mu_law_decode_np(pr.argmax(-1).astype(np.float32)).reshape(2, 1)

@@ -246,3 +246,22 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--probe-ranks'],
                          env=dict(os.environ, WORLD_SIZE='2', RANK='0'), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and 'does not match' in bad.stderr
+
+
+def test_relu_flip_detector():
+    """tests/flips.py: what the model parity tests use to tell a relu mask flipped by summation-order noise from an error."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from flips import describe, relu_flips
+    ref = torch.tensor([[5.0, -3.0, 7.45e-7, -2.0e-7], [1.0, 2.0, -1.0, 0.5]])
+    same = ref.clone()
+    assert relu_flips({'t': (same, ref)}) == [] and 'no relu mask' in describe([])
+    noisy = ref.clone()
+    noisy[0, 2] = -3.0e-7                      # within 2e-6 * 5.0 of zero on both sides: benign
+    f = relu_flips({'skip_sum': (noisy, ref)})
+    assert len(f) == 1 and f[0]['index'] == 2 and f[0]['benign'] and 'skip_sum[2]' in describe(f)
+    wrong = ref.clone()
+    wrong[1, 1] = -2.0                         # a real sign error
+    f = relu_flips({'skip_sum': (wrong, ref)})
+    assert len(f) == 1 and not f[0]['benign'] and 'NOT within noise' in describe(f)
+    with pytest.raises(ValueError):
+        relu_flips({'t': (ref[:1], ref)})

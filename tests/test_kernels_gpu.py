@@ -996,6 +996,15 @@ def test_rowsum_transpose_softmax_adam(K):
     close(ls, loss.detach().reshape(1), rtol=1e-5, atol=1e-5, what='CE loss')
     close(dl, 0.25 * lr.grad, atol=1e-6, rtol=1e-5, what='dlogits')
     close(pr, torch.softmax(lg, 1), atol=1e-6, rtol=1e-5, what='probs')
+    # the same op through the two entries SURVEY 8(b) names: bit-equal to the fused call
+    ls2 = torch.zeros(1, device=DEV); pr2 = torch.full_like(dl, float('nan')); dl2 = torch.full_like(dl, float('nan'))
+    K.softmax_xent_fwd(g(lg), g(lab), loss_sum=ls2, probs=pr2)
+    K.softmax_xent_bwd(g(lg), g(lab), dlogits=dl2, grad_scale=0.25)
+    close(ls2, loss.detach().reshape(1), rtol=1e-5, atol=1e-5, what='CE loss (fwd entry)')
+    assert torch.equal(pr2, pr) and torch.equal(dl2, dl)
+    inplace = g(lg).clone()
+    K.softmax_xent_bwd(inplace, g(lab), dlogits=inplace, grad_scale=0.25)
+    assert torch.equal(inplace, dl)
     # Adam + EMA, two steps, n not a multiple of 4
     n = 1003
     p0, gr = rnd(n, seed=5), rnd(n, seed=6)

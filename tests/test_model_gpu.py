@@ -7,12 +7,16 @@ the reference widths (one relu mask flipped by summation-order noise moves every
 B*T = 1024: DESIGN 6, tools/race_diag3.py); parameters / EMA after the Adam step 1e-4."""
 import importlib.util
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 from oracle import ref_model as M
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from flips import describe, relu_flips  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
@@ -41,16 +45,21 @@ def l2err(a, b):
     return float((a - b).norm()) / max(float(b.norm()), 1e-30)
 
 
-def run_parity(pkg, m, w, S, B, T, seed, steps=1, grad_tol=2e-3, err=relerr, check_params=True, resync=False):
+def run_parity(pkg, m, w, S, B, T, seed, steps=1, grad_tol=2e-3, err=relerr, check_params=True, resync=False, flip_tol=None):
+    """flip_tol: relative-L2 bar that replaces `grad_tol` for a step in which a relu mask of the device differs from the
+    oracle's at an input within summation-order noise of zero (tests/flips.py) -- and only for such a step.  Whatever the
+    outcome, a failing gradient check names the flipped elements (or says that there are none)."""
     P = M.init_params(m, w, S, seed=seed, randomize_all=True)
     x, spk, _ = M.synthetic_batch(B, T, S, 1234)
     model = build(pkg, m, w, S, P)
     xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
     st = {'t': 0, 'm': {}, 'v': {}, 'ema': {}}
+    flipped_steps = []
     for step in range(steps):
         if resync and step:       # start every step from the oracle's parameters (the trajectories of two fp32 evaluations part)
             model.load_named(P, also_ema=False)
-        out, grads = M.train_step(x, spk, P, m, w, st, step)
+        col = {}
+        out, grads = M.train_step(x, spk, P, m, w, st, step, collect=col)
         ws = model.forward(xd, sd, compute_grad_seed=False)
         logits = ws['logits'].permute(0, 2, 1).reshape(-1, model.Q)
         if out['q'] is not None:          # (use_vq = false: no indices)
@@ -58,18 +67,34 @@ def run_parity(pkg, m, w, S, B, T, seed, steps=1, grad_tol=2e-3, err=relerr, che
         assert torch.equal(ws['labels'].cpu().reshape(-1), out['labels']), 'mu-law labels differ'
         assert relerr(ws['z_e'].permute(0, 2, 1), out['z_e']) < 2e-4
         assert relerr(logits, out['logits']) < 5e-4
-        model.train_step(xd, sd)
+        snap = {}
+
+        def relu_inputs(ws_):             # of the forward pass whose gradients are checked (backward overwrites them)
+            snap['skip_sum'] = ws_['skip'].permute(0, 2, 1).clone()
+            snap['post1_pre'] = ws_['h1'].permute(0, 2, 1).clone()
+        model.train_step(xd, sd, on_forward=relu_inputs)
+        pairs = {k: (snap[k], col[k]) for k in snap}
+        if model.enc == '64':
+            pairs.update({'enc_relu_%d' % i: (ws['r'][i].permute(0, 2, 1), col['enc_relu_%d' % i]) for i in range(6)})
+        flips = relu_flips(pairs)
         loss, recon, vq, commit = model.losses(ws)
         np.testing.assert_allclose(recon, out['reconstruction_loss'].item(), rtol=2e-5)
         np.testing.assert_allclose(vq, out['vq_loss'].item() if 'vq_loss' in out else 0.0, rtol=2e-5)
         np.testing.assert_allclose(loss, out['loss'].item(), rtol=2e-5)
         got = model.named_gradients()
         worst = ('', 0.0)
+        benign = bool(flips) and all(f['benign'] for f in flips)
+        if benign and flip_tol is not None:
+            flipped_steps.append(step)
+            print('step %d: relu mask flipped inside summation-order noise: %s' % (step, describe(flips)))
         for name, gref in grads.items():
-            e = err(got[name], gref)
+            if benign and flip_tol is not None:
+                e, tol = l2err(got[name], gref), flip_tol
+            else:
+                e, tol = err(got[name], gref), grad_tol
             if e > worst[1]:
                 worst = (name, e)
-            assert e < grad_tol, 'grad %s rel err %.3e at step %d' % (name, e, step)
+            assert e < tol, 'grad %s err %.3e (bar %.1e) at step %d; %s' % (name, e, tol, step, describe(flips))
         if not check_params:
             continue
         newp = model.named_parameters()
@@ -78,6 +103,7 @@ def run_parity(pkg, m, w, S, B, T, seed, steps=1, grad_tol=2e-3, err=relerr, che
         ema = model.named_parameters(ema=True)
         for name in grads:
             assert err(ema[name], st['ema'][name]) < 1e-4, 'ema %s' % name
+    run_parity.flipped_steps = flipped_steps
     return worst
 
 
@@ -479,15 +505,23 @@ def test_config_variants_use_vq_false_and_one_hot_speakers(pkg, variant):
     """model_parameters.json variants of the reference: use_vq=false (z_q = e_k = z_e, reconstruction loss only,
     no codebook variable: model.py:137-141) and speaker_embedding=0 (the one-hot speaker vector itself is concatenated
     as the global condition: model.py:19-27, decoder_ops.py:39-43; 10 speakers -> a 26-channel condition that the
-    kernels pad to 32).  Two train steps against the oracle, then generation through the padded condition."""
+    kernels pad to 32).  Two train steps against the oracle, then generation through the padded condition.
+
+    Round 2 saw [one_hot_speaker] fail twice in ~14 runs at 5e-3 and widened the bar to 2e-2.  Cause (round 3): in that variant
+    the oracle's skip sum -- the input of the relu before postprocess1, wavenet.py:79-80 -- has an element at 7.45e-07 with a
+    tensor max of 5.5 (1.4e-7 of max = one fp32 ulp of the sum; measured with M.train_step(collect=...)), and this build's forward
+    pass is not bit-reproducible from run to run (the tiny configuration's short encoder layers are split over K with fp32
+    atomics), so that element's relu mask comes out either way; one flipped element moves every gradient by up to ~1e-2 at
+    B*T = 1024.  Not a state leak: the whole GPU suite ran once with VQW_POISON=1 (every workspace buffer NaN at allocation and
+    at the start of every step, _alloc.py) and this test stayed finite and green.  The bar is 5e-3 again; the 2e-2 relative-L2
+    form applies only to a step in which run_parity demonstrates a mask flip within 2e-6 of the tensor max of zero, and it
+    prints the element."""
     m, w = tiny_cfg()
     if variant in ('no_vq', 'both'):
         m = dict(m, use_vq=False)
     if variant in ('one_hot_speaker', 'both'):
         m = dict(m, speaker_embedding=0)
-    # 2e-2 in relative L2: with this seed one relu input sits within summation-order noise of zero (the test failed twice in
-    # ~14 runs of the whole file at 5e-3 of max, never in 8 runs alone); a wiring error of these variants would show as O(1)
-    worst = run_parity(pkg, m, w, 10, 2, 512, seed=31, steps=2, grad_tol=2e-2, err=l2err, resync=True, check_params=False)
+    worst = run_parity(pkg, m, w, 10, 2, 512, seed=31, steps=2, grad_tol=5e-3, resync=True, check_params=False, flip_tol=2e-2)
     P = M.init_params(m, w, 10, seed=31, randomize_all=True)
     assert ('embedding/embedding' in P) == m['use_vq'] and ('speaker_embedding' in P) == (m['speaker_embedding'] > 0)
     model = build(pkg, m, w, 10, P)

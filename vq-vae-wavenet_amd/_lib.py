@@ -129,6 +129,8 @@ SIGNATURES = {
     'vqw_speaker_tile_fwd': (_i, [_fp, _fp, _fp, _i64, _i, _i, _i, _i, _i, _fp]),
     'vqw_speaker_tile_bwd': (_i, [_fp, _i64, _i, _fp, _fp, _i, _i, _i, _i, _fp]),
     'vqw_softmax_xent': (_i, [_fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _fp]),
+    'vqw_softmax_xent_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
+    'vqw_softmax_xent_bwd': (_i, [_fp, _fp, _fp, _f, _i, _i, _i, _fp]),
     'vqw_adam_ema_step': (_i, [_fp, _fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _f, _fp]),
     'vqw_ar_decode_create': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i]),
     'vqw_ar_decode_reset': (_i, [_fp, _fp]),

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
         float loss = ok ? (logf(S) + M - XL) : 0.0f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
-        if (lane == 0) unsafeAtomicAdd(loss_sum, loss);
+        if (lane == 0 && loss_sum) unsafeAtomicAdd(loss_sum, loss);
     }
     if (ok && (dlogits || probs)) {
         const float inv = 1.0f / S;
@@ -640,6 +640,28 @@ extern "C" int vqw_softmax_xent(const float* logits, const int32_t* labels, floa
     VQW_CHECK(B > 0 && T > 0 && Q >= 4 && Q % 4 == 0, "vqw_softmax_xent: Q=%d must be a multiple of 4", Q);
     hipLaunchKernelGGL(softmax_xent_kernel, dim3(B * vqw_cdiv(T, 64)), dim3(256), 0, (hipStream_t)s, logits, labels, dlogits, probs, loss_sum, grad_scale, Q, T);
     VQW_LAUNCH_CHECK("vqw_softmax_xent");
+    return 0;
+}
+
+// The two entries SURVEY 8(b) names, over the same kernel: forward = the loss sum (+ the probabilities), backward = the gradient
+// seed (softmax - onehot) * grad_scale, recomputed from the logits (may be written in place over them).
+extern "C" int vqw_softmax_xent_fwd(const float* logits, const int32_t* labels, float* probs, float* loss_sum, int B, int Q, int T,
+                                    vqw_stream_t s) {
+    VQW_CHECK(logits && labels && loss_sum, "vqw_softmax_xent_fwd: null pointer");
+    VQW_CHECK(B > 0 && T > 0 && Q >= 4 && Q % 4 == 0, "vqw_softmax_xent_fwd: Q=%d must be a multiple of 4", Q);
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(B * vqw_cdiv(T, 64)), dim3(256), 0, (hipStream_t)s, logits, labels, (float*)nullptr, probs,
+                       loss_sum, 0.0f, Q, T);
+    VQW_LAUNCH_CHECK("vqw_softmax_xent_fwd");
+    return 0;
+}
+
+extern "C" int vqw_softmax_xent_bwd(const float* logits, const int32_t* labels, float* dlogits, float grad_scale, int B, int Q, int T,
+                                    vqw_stream_t s) {
+    VQW_CHECK(logits && labels && dlogits, "vqw_softmax_xent_bwd: null pointer");
+    VQW_CHECK(B > 0 && T > 0 && Q >= 4 && Q % 4 == 0, "vqw_softmax_xent_bwd: Q=%d must be a multiple of 4", Q);
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(B * vqw_cdiv(T, 64)), dim3(256), 0, (hipStream_t)s, logits, labels, dlogits, (float*)nullptr,
+                       (float*)nullptr, grad_scale, Q, T);
+    VQW_LAUNCH_CHECK("vqw_softmax_xent_bwd");
     return 0;
 }
 

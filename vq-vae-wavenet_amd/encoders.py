@@ -13,6 +13,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import _alloc as A
 from . import kernels as K
 
 
@@ -73,8 +74,8 @@ class EncoderMagenta:
 
     def scratch(self, dev):
         F, D, L, k = self.FILTERS, self.D, len(self.DIL), self.KS
-        return {'mag_d_w': torch.empty(L, F, F, device=dev), 'mag_gf_w': torch.empty(L, k, 2 * F, F, device=dev),
-                'mag_r_w': torch.empty(L, F, F, device=dev), 'mag_post_w': torch.empty(D, F, device=dev)}
+        return {'mag_d_w': A.empty(L, F, F, device=dev), 'mag_gf_w': A.empty(L, k, 2 * F, F, device=dev),
+                'mag_r_w': A.empty(L, F, F, device=dev), 'mag_post_w': A.empty(D, F, device=dev)}
 
     def transpose(self, P, Tt):
         F, D, L, k = self.FILTERS, self.D, len(self.DIL), self.KS
@@ -85,7 +86,7 @@ class EncoderMagenta:
 
     def workspace(self, ws, B, T, dev, train=True):
         F, L = self.FILTERS, len(self.DIL)
-        e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+        e = lambda *s: A.empty(*s, device=dev)  # noqa: E731
         Tl = [T // (2 ** (i + 1)) for i in range(L)]
         ws['m_Tl'] = Tl
         ws['m_en'] = [e(B, F, T)] + [e(B, F, t) for t in Tl]     # en_0 .. en_6
@@ -222,8 +223,8 @@ class Encoder2019:
 
     def scratch(self, dev):
         F, D = self.F, self.D
-        return {'e19_wk3': torch.empty(7, 3, F, F, device=dev), 'e19_w2': torch.empty(4, F, F, device=dev),
-                'e19_w9': torch.empty(D, F, device=dev), 'e19_mel': mel_weight_matrix().to(dev),
+        return {'e19_wk3': A.empty(7, 3, F, F, device=dev), 'e19_w2': A.empty(4, F, F, device=dev),
+                'e19_w9': A.empty(D, F, device=dev), 'e19_mel': mel_weight_matrix().to(dev),
                 'e19_ones': torch.ones(F, device=dev), 'e19_twos': torch.full((F,), 2.0, device=dev),
                 'e19_zeros': torch.zeros(F, device=dev)}
 
@@ -241,7 +242,7 @@ class Encoder2019:
 
     def workspace(self, ws, B, T, dev, train=True):
         F = self.F
-        e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+        e = lambda *s: A.empty(*s, device=dev)  # noqa: E731
         Fr = T // 160
         Tz = Fr // 2
         ws['e_Fr'] = Fr

@@ -105,16 +105,18 @@ def add_condition(net, condition):
 
 
 def gated_cnn(net, dilation_filters, kernel_size, dilations, local_condition, global_condition):
-    """wavenet_ops.py:104-114."""
-    if global_condition is not None:
-        raise NotImplementedError('the reference passes global_condition=None (decoder.py:35): speakers enter through concat')
+    """wavenet_ops.py:104-114.  The reference's own decoder passes global_condition=None (decoder.py:34-36: speakers enter
+    through concat); a non-None one is a second add_condition under the scope 'global_condition' (:109-110)."""
     kernel = get_variable('kernel', (kernel_size, net.shape[-1], 2 * dilation_filters), _unit_scaling(1.0))
     bias = get_variable('bias', (2 * dilation_filters,), _zeros)
-    ck = None
+    ck = gk = None
     if local_condition is not None:
         with variable_scope('local_condition'):
             ck = get_variable('kernel', (1, local_condition.shape[-1], 2 * dilation_filters), _unit_scaling(1.0))
-    return O.gated_cnn(net, kernel, bias, dilations, local_condition, ck)
+    if global_condition is not None:
+        with variable_scope('global_condition'):
+            gk = get_variable('kernel', (1, global_condition.shape[-1], 2 * dilation_filters), _unit_scaling(1.0))
+    return O.gated_cnn(net, kernel, bias, dilations, local_condition, ck, global_condition, gk)
 
 
 def residual_stack(net, dilation_filters, kernel_size, dilations, skip_filters, residual_filters, local_condition,
@@ -277,6 +279,9 @@ class Wavenet:
             if local_condition is not None:
                 with variable_scope('local_condition'):
                     net = add_condition(net, local_condition)
+            if global_condition is not None:                                   # wavenet.py:89-91
+                with variable_scope('global_condition'):
+                    net = add_condition(net, global_condition)
         with variable_scope('postprocess2'):
             net = conv1d_v2(torch.relu(net), a['quantization_channels'], kernel_size=1)
         self.logits = net.reshape(-1, a['quantization_channels'])
@@ -304,6 +309,8 @@ class Wavenet:
             net = linear(torch.relu(skip), a['skip_filters'])
             with variable_scope('local_condition'):
                 net = fast_condition(net, local_condition_t)
+            with variable_scope('global_condition'):                           # wavenet.py:160-162
+                net = fast_condition(net, global_condition_t)
         with variable_scope('postprocess2'):
             net = linear(torch.relu(net), a['quantization_channels'])
         self.init_ops, self.push_ops = init_ops, push_ops

@@ -515,6 +515,25 @@ def softmax_xent(logits, labels, *, loss_sum, dlogits=None, probs=None, grad_sca
                                      float(grad_scale), B, Q, T, L.stream()))
 
 
+def softmax_xent_fwd(logits, labels, *, loss_sum, probs=None):
+    """vqw_softmax_xent_fwd: loss_sum[0] += sum of the cross-entropies (model.py:91-94); probs optional."""
+    B, Q, T = logits.shape
+    L.require_cuda(logits, labels, loss_sum, probs)
+    if labels.dtype != torch.int32 or labels.numel() != B * T:
+        raise ValueError('labels must be int32 [B][T]')
+    L.check(L.lib().vqw_softmax_xent_fwd(L.ptr(logits), L.ptr(labels), L.ptr(probs), L.ptr(loss_sum), B, Q, T, L.stream()))
+
+
+def softmax_xent_bwd(logits, labels, *, dlogits, grad_scale=1.0):
+    """vqw_softmax_xent_bwd: dlogits = (softmax(logits) - onehot(labels)) * grad_scale (may alias logits)."""
+    B, Q, T = logits.shape
+    L.require_cuda(logits, labels, dlogits)
+    if labels.dtype != torch.int32 or labels.numel() != B * T:
+        raise ValueError('labels must be int32 [B][T]')
+    _need(dlogits, B * Q * T, 'dlogits')
+    L.check(L.lib().vqw_softmax_xent_bwd(L.ptr(logits), L.ptr(labels), L.ptr(dlogits), float(grad_scale), B, Q, T, L.stream()))
+
+
 def adam_ema_step(param, grad, m, v, ema, *, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, decay=0.999,
                   grad_scale=1.0):
     n = param.numel()

@@ -17,6 +17,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import _alloc as A
 from . import kernels as K
 from .encoders import Encoder2019, EncoderMagenta
 
@@ -232,17 +233,24 @@ class VQVAE:
         self.ema = self.flat.clone()     # ExponentialMovingAverage shadows start at the variables
         self.E = self._views(self.ema)
         # scratch: per-tap transposed kernels for the input-gradient GEMMs
+        self._poison_T = []
+        with A.record(self._poison_T):
+            self._alloc_scratch()
+
+    def _alloc_scratch(self):
+        dev = self.dev
+        F, D, R, S, Q, L, ks, Cc = self.F, self.D, self.R, self.S, self.Q, self.L, self.ks, self.Cc
         self.T = {
-            'gated_w': torch.empty(L, ks, 2 * R, R, device=dev),
-            'out_w': torch.empty(L, S + R, R, device=dev),
-            'post1_w': torch.empty(S, S, device=dev),
-            'post2_w': torch.empty(Q, S, device=dev),
-            'skip0_w': torch.empty(S, R, device=dev),
-            'cond_w': torch.empty(self.Mall, Cc, device=dev),
+            'gated_w': A.empty(L, ks, 2 * R, R, device=dev),
+            'out_w': A.empty(L, S + R, R, device=dev),
+            'post1_w': A.empty(S, S, device=dev),
+            'post2_w': A.empty(Q, S, device=dev),
+            'skip0_w': A.empty(S, R, device=dev),
+            'cond_w': A.empty(self.Mall, Cc, device=dev),
         }
         if self.enc == '64':
-            self.T['enc_w'] = torch.empty(5, 5, F, F, device=dev)
-            self.T['enc_w6'] = torch.empty(D, F, device=dev)
+            self.T['enc_w'] = A.empty(5, 5, F, F, device=dev)
+            self.T['enc_w6'] = A.empty(D, F, device=dev)
         else:
             self.T.update(self.magenta.scratch(dev))
 
@@ -326,6 +334,14 @@ class VQVAE:
             return self._ws[key]
         if not train and (B, T, True) in self._ws:
             return self._ws[(B, T, True)]
+        rec = []
+        with A.record(rec):
+            ws = self._build_workspace(B, T, train)
+        ws['_poison'] = rec          # (VQW_POISON=1: refilled with NaN at the start of every step)
+        self._ws[key] = ws
+        return ws
+
+    def _build_workspace(self, B, T, train):
         if self.enc == '64':
             if T % 64 != 0:
                 raise ValueError('length must be a multiple of 64 for Encoder_64 (got %d)' % T)
@@ -333,20 +349,20 @@ class VQVAE:
         else:
             Tz = self.magenta.latent_len(T)
         dev, F, D, R, S, Q, L = self.dev, self.F, self.D, self.R, self.S, self.Q, self.L
-        e = lambda *s: torch.empty(*s, device=dev)  # noqa: E731
+        e = lambda *s: A.empty(*s, device=dev)  # noqa: E731
         ws = {'B': B, 'T': T, 'Tz': Tz, 'ratio': T // Tz}
         ws['Tl'] = [T // (2 ** (i + 1)) for i in range(6)]
         ws['inputs'] = e(B, T)
-        ws['labels'] = torch.empty(B, T, dtype=torch.int32, device=dev)
+        ws['labels'] = A.empty(B, T, dtype=torch.int32, device=dev)
         if self.enc == '64':
             ws['X'] = [e(B, F, t) for t in ws['Tl']]      # BN outputs of encoder layers 0..5
             if self.x3_guard and not self.bf16 and F % 256 == 0:      # fp16x3 engine for layers 1..3 (_enc_x3_layers)
-                ws['eplanes'] = torch.empty(2 * B * F * ws['Tl'][0], dtype=torch.float16, device=dev)   # planes of one layer's operand
-                ws['ewp'] = torch.empty(5, 2 * 5 * F * F, dtype=torch.float16, device=dev)
+                ws['eplanes'] = A.empty(2 * B * F * ws['Tl'][0], dtype=torch.float16, device=dev)   # planes of one layer's operand
+                ws['ewp'] = A.empty(5, 2 * 5 * F * F, dtype=torch.float16, device=dev)
                 ws['enc_amax'] = torch.zeros(12, dtype=torch.int32, device=dev)
                 ws['enc_scale'] = torch.ones(12, device=dev)
                 if train:
-                    ws['ewtp'] = torch.empty(5, 2 * 5 * F * F, dtype=torch.float16, device=dev)
+                    ws['ewtp'] = A.empty(5, 2 * 5 * F * F, dtype=torch.float16, device=dev)
             if train:
                 ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
                 ws['y6'] = e(B, D, Tz)
@@ -354,14 +370,13 @@ class VQVAE:
         else:
             self.magenta.workspace(ws, B, T, dev, train)
         ws['z_e'] = e(B, D, Tz)
-        ws['idx'] = torch.empty(B, Tz, dtype=torch.int64, device=dev)
+        ws['idx'] = A.empty(B, Tz, dtype=torch.int64, device=dev)
         ws['e_k'] = e(B, D, Tz)
         ws['mind'] = e(B, Tz)
         ws['cond'] = e(B, self.Cc, Tz)
         ws['scale'] = e(6 * F + D)
         ws['shift'] = e(6 * F + D)
         if not train:
-            self._ws[key] = ws
             return ws
         ws['condenc'] = e(B, self.Mall, Tz)
         ws['net'] = [e(B, R, T) for _ in range(L + 1)]
@@ -370,29 +385,29 @@ class VQVAE:
         ws['th'] = [e(B, R, T) for _ in range(L)]
         ws['sg'] = [e(B, R, T) for _ in range(L)]
         if self.gate_f16x3:
-            ws['xp'] = torch.empty(2 * B * R * T, dtype=torch.float16, device=dev)
-            ws['wp_all'] = torch.empty(L, 2 * self.ks * R * 2 * R, dtype=torch.float16, device=dev)
+            ws['xp'] = A.empty(2 * B * R * T, dtype=torch.float16, device=dev)
+            ws['wp_all'] = A.empty(L, 2 * self.ks * R * 2 * R, dtype=torch.float16, device=dev)
             ws['wp'] = [ws['wp_all'][l] for l in range(L)]
-            ws['gp'] = torch.empty(2 * B * R * T * (L if self.skip_f16x3 else 1), dtype=torch.float16, device=dev)
+            ws['gp'] = A.empty(2 * B * R * T * (L if self.skip_f16x3 else 1), dtype=torch.float16, device=dev)
             if self.dgrad_f16x3:
-                ws['dp'] = torch.empty(2 * B * 2 * R * T, dtype=torch.float16, device=dev)
-                ws['wdg'] = torch.empty(L, 2 * self.ks * 2 * R * R, dtype=torch.float16, device=dev)
+                ws['dp'] = A.empty(2 * B * 2 * R * T, dtype=torch.float16, device=dev)
+                ws['wdg'] = A.empty(L, 2 * self.ks * 2 * R * R, dtype=torch.float16, device=dev)
                 if self.gbwd_f16x3:
-                    ws['gr'] = torch.empty(2 * B * (S + R) * T, dtype=torch.float16, device=dev)   # [dskip | dnet] lifted planes
-                    ws['wgb'] = torch.empty(L, 2 * (S + R) * R, dtype=torch.float16, device=dev)
-                    ws['wgb_top'] = torch.empty(2 * S * R, dtype=torch.float16, device=dev)
+                    ws['gr'] = A.empty(2 * B * (S + R) * T, dtype=torch.float16, device=dev)   # [dskip | dnet] lifted planes
+                    ws['wgb'] = A.empty(L, 2 * (S + R) * R, dtype=torch.float16, device=dev)
+                    ws['wgb_top'] = A.empty(2 * S * R, dtype=torch.float16, device=dev)
             if self.skip_f16x3:
-                ws['wskip'] = torch.empty(2 * L * R * S, dtype=torch.float16, device=dev)
-                ws['wres'] = torch.empty(L, 2 * R * R, dtype=torch.float16, device=dev)
+                ws['wskip'] = A.empty(2 * L * R * S, dtype=torch.float16, device=dev)
+                ws['wres'] = A.empty(L, 2 * R * R, dtype=torch.float16, device=dev)
                 if self.x3_guard and self.gbwd_f16x3 and S % 256 == 0 and Q % 256 == 0:     # the convs around the stack on the engine too
-                    ws['hp'] = torch.empty(2 * B * S * T, dtype=torch.float16, device=dev)     # relu(skip) / d postprocess1 planes
-                    ws['hp2'] = torch.empty(2 * B * S * T, dtype=torch.float16, device=dev)    # relu(postprocess1) / d logits planes
+                    ws['hp'] = A.empty(2 * B * S * T, dtype=torch.float16, device=dev)     # relu(skip) / d postprocess1 planes
+                    ws['hp2'] = A.empty(2 * B * S * T, dtype=torch.float16, device=dev)    # relu(postprocess1) / d logits planes
                     for name, n_ in (('wskip0', R * S), ('wpost1', S * S), ('wpost2', S * Q)):
-                        ws[name] = torch.empty(2 * n_, dtype=torch.float16, device=dev)
-                        ws[name + 't'] = torch.empty(2 * n_, dtype=torch.float16, device=dev)
+                        ws[name] = A.empty(2 * n_, dtype=torch.float16, device=dev)
+                        ws[name + 't'] = A.empty(2 * n_, dtype=torch.float16, device=dev)
                     # |d loss / d logits| <= 1 / (B T): a fixed power-of-two scale, max-abs below 2^13
                     ws['dl_scale'] = torch.full((1,), 2.0 ** math.floor(math.log2(2.0 ** 13 * B * T)), device=dev)
-            ws['wop_all'] = torch.empty(L, 2 * R * (S + R), dtype=torch.float16, device=dev)
+            ws['wop_all'] = A.empty(L, 2 * R * (S + R), dtype=torch.float16, device=dev)
             ws['wop'] = [ws['wop_all'][l] for l in range(L)]
         ws['h1'] = e(B, S, T)
         ws['logits'] = e(B, Q, T)
@@ -406,7 +421,6 @@ class VQVAE:
         ws['dz'] = e(B, D, Tz)
         ws['bskip'] = e(S)
         ws['dscale'] = e(6 * F + D)
-        self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------ forward pieces
@@ -476,6 +490,15 @@ class VQVAE:
             return ()                                                                   #  range flag is read by train_step)
         B, Tl = ws['B'], ws['Tl']
         return tuple(i for i in (1, 2, 3, 4, 5) if B * Tl[i] >= 256 and Tl[i - 1] == 2 * Tl[i])
+
+    def _wslab(self, ws):
+        """Slab of the engine's weight-gradient kernels: the partial 256x256 tiles of ONE launch.  The launcher cuts K so that
+        tiles x K splits <= the device's CU count (vqw_device_cus), hence one 256x256 fp32 tile per CU."""
+        if 'wslab' not in ws:
+            cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            ws['wslab'] = A.empty(cus * 65536, device=self.dev)
+            ws['_poison'].append(ws['wslab'])
+        return ws['wslab']
 
     def _side_stream(self):
         if self._side is None:
@@ -618,6 +641,8 @@ class VQVAE:
         loss sums in self.loss_buf (no host sync)."""
         B, T = x.shape
         ws = self._workspace(B, T)
+        if A.POISON:             # debug: every workspace buffer and the transposed-kernel scratch start the step as NaN
+            A.repoison(ws['_poison'] + self._poison_T)
         self._encode(x, spk, ws)
         self._decode_train(x, ws)
         self.loss_buf.zero_()
@@ -705,8 +730,7 @@ class VQVAE:
             hsc = lambda name: self.x3_scale[self.SL[name]:self.SL[name] + 1]      # noqa: E731
             ham = lambda name: self.x3_amax[self.SL[name]:self.SL[name] + 1]       # noqa: E731
             mdh, dl, hflag = self.x3_mode_bwd, ws['dl_scale'], self.x3_flag
-            if 'wslab' not in ws:
-                ws['wslab'] = torch.empty(256 * 65536, device=self.dev)
+            self._wslab(ws)
             K.f16x3_pack_weights(Tt['post2_w'], ws['wpost2t'], Q, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
             K.f16x3_pack_weights(Tt['post1_w'], ws['wpost1t'], S, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
             K.f16x3_pack_weights(Tt['skip0_w'], ws['wskip0t'], S, R, R, 1.0, scale_dev=hsc('WH'), mode=mdh)
@@ -735,7 +759,7 @@ class VQVAE:
                 K.f16x3_amax(h1, self.x3_amax[self.SL['DH']:self.SL['DH'] + 1])
             # ---- postprocess1 (wavenet.py:79-88)
             K.wgrad_gemm(p=skip, p_relu=True, q0=h1, dw=G['post1_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=S, taps=[0])
-            seg_p1 = torch.empty(B, S, Tz, device=self.dev)
+            seg_p1 = A.empty(B, S, Tz, device=self.dev)
             K.rowsum(h1, seg_out=seg_p1, total=G['post1_b'], seg=ratio)
             dce[:, L * 2 * R:].copy_(seg_p1)
             K.conv_gemm(x0=h1, w=Tt['post1_w'], out0=skip, aux0=skip, B=B, T_in=T, T_out=T, M=S, C0=S, taps=[0],
@@ -743,7 +767,7 @@ class VQVAE:
         dskip = skip
         # ---- residual stack, top layer first (wavenet.py:63-74)
         net = ws['net']
-        seg_l = torch.empty(B, 2 * R, Tz, device=self.dev)
+        seg_l = A.empty(B, 2 * R, Tz, device=self.dev)
         # Two streams: the chain gate-backward -> input gradient -> next layer stays on the current stream, the
         # weight gradients and bias/condition sums of a layer (which nothing downstream waits for) run on a side
         # stream, so one kernel's thin last round is filled by the other's blocks.  dnet / dpre are rings (3 / 2
@@ -771,8 +795,8 @@ class VQVAE:
         th_dropped = bool(ws.get('th_dropped'))
         if th_dropped and not gbwd_x3:
             raise RuntimeError('the forward pass did not store tanh but gate backward is not on the fp16x3 engine')
-        if wg_x3 and 'wslab' not in ws:
-            ws['wslab'] = torch.empty(256 * 65536, device=self.dev)      # partial 256x256 tiles of one launch (tiles x K splits <= CUs)
+        if wg_x3:
+            self._wslab(ws)
         if dgrad_x3:
             K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, WS, count=L, scale_dev=sc('WG'), mode=md)
         if gbwd_x3:
@@ -995,8 +1019,9 @@ class VQVAE:
         self.global_step = t
         return lr
 
-    def train_step(self, x, spk):
-        """One sess.run(train_op) (train.py:104-114).  With self.grad_sync set (data parallel)
+    def train_step(self, x, spk, on_forward=None):
+        """One sess.run(train_op) (train.py:104-114).  on_forward(ws): called between the forward and the backward pass of the
+        step that is kept (tests snapshot the relu inputs there: backward overwrites them in place).  With self.grad_sync set (data parallel)
         the flat gradient is sum-all-reduced over RCCL in buckets that overlap the backward pass, and averaged.
         Guarded fp16x3 engine: the step's range flag is read before the optimiser runs (one host sync per step); a
         step whose planes left fp16's range is repeated on the fp32 engine, which also measures the max-abs values the
@@ -1004,6 +1029,8 @@ class VQVAE:
         if self.x3_guard:
             self.x3_flag.zero_()
         ws = self.forward(x, spk)
+        if on_forward is not None:
+            on_forward(ws)
         self.backward(x, spk, ws)
         world = self.grad_sync.finish() if self.grad_sync is not None else 1
         if self.bf16 and ws.get('x3_used'):
@@ -1019,6 +1046,8 @@ class VQVAE:
                         K.f16x3_amax(ws['net'][l], self.x3_amax[self.SL['X'] + l:self.SL['X'] + l + 1])
                     K.f16x3_amax(ws['skip'], self.x3_amax[self.SL['SK']:self.SL['SK'] + 1])
                     K.f16x3_amax(ws['h1'], self.x3_amax[self.SL['H1']:self.SL['H1'] + 1])
+                    if on_forward is not None:
+                        on_forward(ws)
                     self.backward(x, spk, ws)
                     world = self.grad_sync.finish() if self.grad_sync is not None else 1
                 finally:

@@ -130,36 +130,61 @@ def add_condition(net, condition, kernel):
     if condition is None:
         return net
     B, T, C = net.shape
-    Tz, Cc = condition.shape[1], condition.shape[2]
-    enc = torch.empty(B, C, Tz, device=net.device)
-    K.conv_gemm(x0=_bct(condition), w=kernel.reshape(Cc, C).contiguous(), out0=enc, B=B, T_in=Tz, T_out=Tz, M=C,
-                C0=Cc, taps=[0])
+    Tz = condition.shape[1]
+    enc = _condition_projection(condition, kernel, C)
     return (net.reshape(B, Tz, T // Tz, C) + _btc(enc).unsqueeze(2)).reshape(B, T, C)
 
 
-def gated_cnn(net, kernel, bias, dilations, local_condition=None, cond_kernel=None):
-    """wavenet_ops.py:104-114: causal dilated conv -> +condition -> tanh(first half)*sigmoid(second)."""
+def _condition_projection(condition, cond_kernel, C):
+    """The 1x1 (no bias) of add_condition (wavenet_ops.py:97) -> [B, C, T_cond] in the kernels' layout."""
+    B, Tc, Cc = condition.shape
+    enc = torch.empty(B, C, Tc, device=condition.device)
+    K.conv_gemm(x0=_bct(condition), w=cond_kernel.reshape(Cc, C).contiguous(), out0=enc, B=B, T_in=Tc, T_out=Tc, M=C,
+                C0=Cc, taps=[0])
+    return enc
+
+
+def _merged_condition(net_len, C, conditions):
+    """Projections of several conditions (local [B, Tz, Cc], global [B, Tg, Cg], ...) as ONE [B, C, Tc] operand of the conv
+    epilogue's upsampled add: each is repeated up to the common frame count Tc = lcm(Tz, Tg) and they are summed, which is
+    what the consecutive add_condition calls of wavenet_ops.py:107-110 amount to (net_len % Tc == 0 as their reshapes need)."""
+    import math
+    encs = [_condition_projection(c, k, C) for c, k in conditions if c is not None]
+    if not encs:
+        return None
+    Tc = 1
+    for e in encs:
+        Tc = Tc * e.shape[2] // math.gcd(Tc, e.shape[2])
+    if net_len % Tc != 0:
+        raise ValueError('condition lengths %s do not divide the sequence length %d' % ([e.shape[2] for e in encs], net_len))
+    out = None
+    for e in encs:
+        e = e if e.shape[2] == Tc else e.repeat_interleave(Tc // e.shape[2], dim=2)
+        out = e if out is None else out + e
+    return out.contiguous()
+
+
+def gated_cnn(net, kernel, bias, dilations, local_condition=None, cond_kernel=None, global_condition=None, global_kernel=None):
+    """wavenet_ops.py:104-114: causal dilated conv -> +local condition -> +global condition -> tanh(first half)*sigmoid(second)."""
     B, T, Cin = net.shape
     k, _, C2 = kernel.shape
     H = C2 // 2
     out = torch.empty(B, H, T, device=net.device)
     kw = {}
-    if local_condition is not None:
-        Tz, Cc = local_condition.shape[1], local_condition.shape[2]
-        enc = torch.empty(B, C2, Tz, device=net.device)
-        K.conv_gemm(x0=_bct(local_condition), w=cond_kernel.reshape(Cc, C2).contiguous(), out0=enc, B=B, T_in=Tz,
-                    T_out=Tz, M=C2, C0=Cc, taps=[0])
-        kw = dict(cond=enc, cond_T=Tz)
+    enc = _merged_condition(T, C2, [(local_condition, cond_kernel), (global_condition, global_kernel)])
+    if enc is not None:
+        kw = dict(cond=enc, cond_T=enc.shape[2])
     K.conv_gemm(x0=_bct(net), w=kernel.contiguous(), bias=bias, out0=out, B=B, T_in=T, T_out=T, M=C2, C0=Cin,
                 taps=[-(k - 1 - j) * dilations for j in range(k)], epilogue=K.EPI_GATE, **kw)
     return _btc(out)
 
 
-def residual_stack(net, params, dilations, local_condition=None):
+def residual_stack(net, params, dilations, local_condition=None, global_condition=None):
     """wavenet_ops.py:117-138 -> (skip_connection, residual_connection).
-    params: gated/{kernel,bias}, gated/local_condition/kernel, skip/{kernel,bias}, residual/{kernel,bias}."""
+    params: gated/{kernel,bias}, gated/local_condition/kernel, gated/global_condition/kernel, skip/{kernel,bias},
+    residual/{kernel,bias}."""
     gated = gated_cnn(net, params['gated/kernel'], params['gated/bias'], dilations, local_condition,
-                      params.get('gated/local_condition/kernel'))
+                      params.get('gated/local_condition/kernel'), global_condition, params.get('gated/global_condition/kernel'))
     skip = conv1d_v2(gated, params['skip/kernel'], params['skip/bias'])
     res = conv1d_v2(gated, params['residual/kernel'], params['residual/bias'])
     return skip, res
