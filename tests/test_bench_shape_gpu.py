@@ -108,6 +108,68 @@ def test_bench_workload_full_step_matches_oracle(pkg, monkeypatch, engine):
     torch.cuda.empty_cache()
 
 
+def test_batch_16_runs_on_the_fp16x3_engine(pkg, monkeypatch, capfd):
+    """Round 2 turned the whole engine off for B*T > 69 905 (32-bit offsets over the all-layers gated planes) and the step ran
+    silently on the fp32 engine.  The planes are now addressed through one buffer resource per plane, based at the
+    contraction's first chunk, and a skip contraction longer than 2 GiB per plane is cut into layer groups:
+    * reference widths, B = 16, T = 1024 with the skip contraction FORCED into 3 layer groups: one step against the oracle at
+      the bars of the bench-shape test;
+    * `-batch 16 -length 6656` (B*T = 106 496, planes of 3.3 GB): the step runs on the fp16x3 engine, no range fallback, and
+      agrees with the same step on the fp32-MFMA engine (losses 2e-5, gradients 5e-3 relative L2);
+    * a shape the engine cannot take says so on stderr, once."""
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    P0 = M.init_params(m, w, 109, seed=4, randomize_all=True)
+    x, spk, _ = M.synthetic_batch(16, 1024, 109, 99)
+    P = {k: v.clone() for k, v in P0.items()}
+    out, grads = M.train_step(x, spk, P, m, w, {'t': 0, 'm': {}, 'v': {}, 'ema': {}}, 0)
+    monkeypatch.setenv('VQW_SKIP_GROUPS', '3')
+    model = pkg.model.VQVAE(m, w, 109, device='cuda', seed=0)
+    model.load_named(P0)
+    xd, sd = x[:, :, 0].contiguous().cuda(), spk.cuda()
+    ws = model.forward(xd, sd, compute_grad_seed=False)
+    assert ws['skip_groups'] == 3 and ws['x3_used']
+    assert torch.equal(ws['idx'].cpu(), out['q']) and torch.equal(ws['labels'].cpu().reshape(-1), out['labels'])
+    assert relerr(ws['logits'].permute(0, 2, 1).reshape(-1, model.Q), out['logits']) < 5e-4
+    ws = model.train_step(xd, sd)
+    assert ws['x3_used'] and model.x3_fallbacks == 0
+    np.testing.assert_allclose(model.losses(ws)[0], out['loss'].item(), rtol=2e-5)
+    got = model.named_gradients()
+    for name, gref in grads.items():
+        assert l2err(got[name], gref) < 5e-3, 'grad %s rel L2 err %.3e' % (name, l2err(got[name], gref))
+    monkeypatch.delenv('VQW_SKIP_GROUPS')
+    del model, ws, got
+    torch.cuda.empty_cache()
+    # ---- batch 16 x 6656 on both engines
+    bench = _bench()
+    mb, wb = bench.default_configs()
+    xb, sb = bench.synthetic_batch(16, 6656, 109, 4321, 'cuda')
+    res = {}
+    for engine in ('f16x3', 'fp32'):
+        monkeypatch.setenv('VQW_ENGINE', engine)
+        mdl = pkg.model.VQVAE(mb, wb, 109, device='cuda', seed=0)
+        wsb = mdl.train_step(xb, sb)
+        assert bool(wsb['x3_used']) == (engine == 'f16x3') and mdl.x3_fallbacks == 0
+        if engine == 'f16x3':
+            assert wsb['skip_groups'] == 1          # 1.6 GB per plane: one contraction
+        res[engine] = (mdl.losses(wsb), {k: v.cpu() for k, v in mdl.named_gradients().items()}, wsb['idx'].cpu())
+        del mdl, wsb
+        torch.cuda.empty_cache()
+    assert torch.equal(res['f16x3'][2], res['fp32'][2])
+    np.testing.assert_allclose(res['f16x3'][0], res['fp32'][0], rtol=2e-5)
+    for name, gref in res['fp32'][1].items():
+        assert l2err(res['f16x3'][1][name], gref) < 5e-3, 'batch 16: grad %s differs between the engines by %.3e' % (name, l2err(res['f16x3'][1][name], gref))
+    # ---- a shape the engine cannot take is reported, once
+    monkeypatch.setenv('VQW_ENGINE', 'f16x3')
+    mdl = pkg.model.VQVAE(mb, wb, 109, device='cuda', seed=0)
+    capfd.readouterr()
+    xs, ss = bench.synthetic_batch(1, 6656 - 128, 109, 1, 'cuda')       # 6528 = 64 * 102: not a multiple of 256
+    for _ in range(2):
+        wss = mdl.train_step(xs, ss)
+    assert not wss['x3_used']
+    err = capfd.readouterr().err
+    assert err.count('runs on the fp32-MFMA engine') == 1 and 'not a multiple of 256' in err
+
+
 @pytest.mark.parametrize('persistent', ['1', '0'])
 def test_fast_generation_reference_width_rings_wrap(pkg, monkeypatch, persistent):
     monkeypatch.setenv('VQW_AR_PERSISTENT', persistent)

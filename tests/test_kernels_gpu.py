@@ -733,7 +733,10 @@ def test_gate_backward_f16x3_from_tanh_or_from_gated(K, half):
     w = (torch.randn(S + R, R, generator=gen) * 0.05).to(DEV)
     xf, xg = torch.randn(B, R, T, generator=gen).to(DEV) * 2, torch.randn(B, R, T, generator=gen).to(DEV) * 3
     xg[:, ::7, ::5] = -200.0                                              # sigmoid == 0 exactly
+    xg[:, 3::7, 1::5] = -88.0                                             # sigmoid = 6e-39: DENORMAL (v_rcp_f32 of it is inf, g^2 is 0)
+    xg[:, 5::7, 2::5] = -87.0                                             # 1.6e-38: the smallest normal numbers
     th, sg = torch.tanh(xf), torch.sigmoid(xg)
+    assert 0 < float(sg[:, 3::7, 1::5].max()) < 1.1754944e-38
     gated = th * sg
     md = K.X3_HALF_BLOCKS if half else 0
     sc = torch.tensor([2.0 ** 28, 64.0, 2.0 ** 26], device=DEV)

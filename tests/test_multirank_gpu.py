@@ -61,6 +61,54 @@ def test_two_ranks_average_to_full_batch_step(pkg, tmp_path):
     assert not torch.equal(r0['grad_sum'], g_full)        # it really was a sum of two different shards
 
 
+def test_range_flag_of_one_rank_makes_every_rank_repeat_the_step(pkg, tmp_path):
+    """The guarded fp16x3 engine under data parallelism (model.train_step / _x3_overflowed): rank 1's residual stream leaves
+    fp16's range, rank 0's (silence) does not; the flag is MAX-all-reduced, BOTH ranks repeat the step on the fp32 engine --
+    exchanging their gradient buckets a second time -- and end with bit-identical parameters, equal to the full-batch step."""
+    run_ranks([os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path), 'gloo', 'guard'], 2)
+    r0 = torch.load(str(tmp_path / 'rank0.pt'), weights_only=True)
+    r1 = torch.load(str(tmp_path / 'rank1.pt'), weights_only=True)
+    assert bool(r0['x3_guard']) and bool(r1['x3_guard'])
+    assert int(r0['own_flag']) == 0 and int(r1['own_flag']) != 0, 'the set-up must overflow on rank 1 only'
+    assert int(r0['fallbacks']) == 1 and int(r1['fallbacks']) == 1, 'both ranks must repeat the step'
+    assert not bool(r0['x3_used']) and not bool(r1['x3_used'])          # the step that was kept ran on the fp32 engine
+    assert torch.isfinite(r0['grad_sum']).all()
+    assert torch.equal(r0['grad_sum'], r1['grad_sum']), 'ranks hold different reduced gradients'
+    assert torch.equal(r0['flat'], r1['flat']) and torch.equal(r0['ema'], r1['ema']), 'ranks diverged after the step'
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_worker
+    m, w, P, x, spk = dp_worker.guard_problem()
+    full = pkg.model.VQVAE(m, w, 10, device='cuda', seed=0)
+    full.load_named(P)
+    full.train_step(x.cuda(), spk.cuda())
+    assert full.x3_fallbacks == 1
+    g_full, g_avg = full.grad.cpu().double(), r0['grad_sum'].double() / 2
+    assert float((g_avg - g_full).norm()) < 1e-4 * float(g_full.norm()), 'sum / world != full-batch gradient'
+
+
+def test_one_rank_on_rccl_runs_the_bucketed_exchange(pkg, tmp_path):
+    """RCCL itself, on the one GPU this box has: a fresh child with WORLD_SIZE=1, backend nccl, GradAllReduce(force=True).
+    The decoder bucket, the per-layer encoder buckets and the rest are all-reduced on the side stream by the real
+    communicator and the flag MAX-all-reduce runs on it too (the step is flagged and repeated: every bucket goes twice).
+    A 1-rank sum is the identity: every bucket comes back bit-identical, the buckets tile [0, n_flat) exactly once per
+    pass, and the step equals the same step without a grad_sync (not bitwise: the fp32 engine's split-K atomics make two
+    evaluations differ in the last bits)."""
+    run_ranks([os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path), 'nccl', 'rccl1'], 1)
+    r = torch.load(str(tmp_path / 'rccl1.pt'), weights_only=True)
+    assert bytes(r['backend'].tolist()).decode() == 'nccl'
+    assert bool(r['identical']), 'a bucket changed under a 1-rank all-reduce'
+    n = int(r['n_flat'])
+    cover = torch.zeros(n, dtype=torch.int32)
+    for lo, hi in r['buckets'].tolist():
+        cover[lo:hi] += 1
+    assert len(r['buckets']) >= 3 and bool((cover == 1).all()), 'buckets must tile the flat gradient exactly once'
+    assert r['fallbacks'].tolist() == [1, 1] and int(r['max_calls']) == 1
+    g, gp = r['grad'].double(), r['grad_plain'].double()
+    assert float((g - gp).norm()) < 1e-5 * float(gp.norm())
+    assert abs(float(r['loss'][0]) - float(r['loss'][1])) <= 1e-6 * abs(float(r['loss'][1]))
+    assert float((r['flat'] - r['flat_plain']).abs().max()) < 1e-5
+
+
 def _tiny_checkpoint(tmp_path):
     w = {"verbose": False, "quantization_channels": 256, "num_cycles": 1, "num_cycle_layers": 4,
          "dilation_rates": [1, 2, 4, 8], "kernel_size": 3, "dilation_filters": 32, "skip_filters": 64,

@@ -315,7 +315,15 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem,
     const int KCA = (TAB ? g.wks : g.ks) * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
     const int nsteps = g.ks * spt;
     const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(g.wp, (unsigned)((size_t)2 * KCA * g.M * 16));
-    const __amdgpu_buffer_rsrc_t rb = vqw_make_rsrc(g.xp, (unsigned)((size_t)2 * g.xKC * g.NB * 16));
+    // One buffer resource per activation plane, based at the contraction's first chunk: 32-bit offsets then only span the
+    // chunks this contraction reads (checked by the callers: Cin / 8 * NB * 16 < 2 GiB), not the planes tensor -- the gated planes
+    // of all layers side by side are 3.3 GB at batch 16 and neither their size nor the distance between the two planes may
+    // decide whether the engine can run.
+    const size_t plane_bytes = (size_t)g.xKC * g.NB * 16, span = (size_t)(g.xKC - g.xkc0) * g.NB * 16;
+    const char* xbase = reinterpret_cast<const char*>(g.xp) + (size_t)g.xkc0 * g.NB * 16;
+    const unsigned xspan = span < 0x7fffffffu ? (unsigned)span : 0x7fffffffu;
+    const __amdgpu_buffer_rsrc_t rb0 = vqw_make_rsrc(xbase, xspan);
+    const __amdgpu_buffer_rsrc_t rb1 = vqw_make_rsrc(xbase + (NP > 1 ? plane_bytes : 0), xspan);
     // Stage image: MR*2 weight pieces (row tile i, plane p at (i * 2 + p) KiB), then 16 activation pieces.  lane = (k half, row)
     // as the MFMA wants it.
     int voffA[NA], pieceA[NA], voffB[NBP], trow[NBP], pieceB[NBP];
@@ -329,7 +337,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem,
     for (int i = 0; i < NBP; ++i) {
         const int q = wv * NBP + i, tile = q / NP, p = q % NP;
         pieceB[i] = tile * 2 + p;
-        voffB[i] = ((p * g.xKC + g.xkc0 + lhi) * g.NB + g.n0 + tile * 32 + l31) * 16;
+        voffB[i] = (lhi * g.NB + g.n0 + tile * 32 + l31) * 16;      // (plane p = i % NP: its own resource)
         trow[i] = TAB ? (g.n0 + tile * 32 + l31) % g.T : g.t0 + tile * 32 + l31;      // time of this lane's activation row
     }
     f32x4 rgA[NA + NBP], rgB[NA + NBP];
@@ -351,7 +359,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem,
         for (int i = 0; i < NBP; ++i) {
             const int tr = trow[i] - shift;
             const int vb = (tr >= 0 && tr < g.T) ? voffB[i] + (kcx * g.NB - shift) * 16 : (int)0x80000000;   // out of range -> 0
-            rg[NA + i] = vqw_buf_load4(rb, vb, 0);
+            rg[NA + i] = vqw_buf_load4((i % NP) ? rb1 : rb0, vb, 0);      // (wv * NBP is even: plane = i % NP at compile time)
         }
     };
     auto rcommit = [&](int s, const f32x4 (&rg)[NA + NBP]) {
@@ -746,7 +754,9 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
                         // th[][] holds g = tanh * sigmoid (the forward pass did not store tanh):
                         //   sg (1 - tanh^2) = sg - g^2 / sg  (0 where the sigmoid underflowed),   tanh sg (1 - sg) = g (1 - sg)
                         const float g_ = th[j][e], sv = sg[j][e];
-                        const float ff = sv > 0.0f ? sv - g_ * g_ * __builtin_amdgcn_rcpf(sv) : 0.0f;
+                        // (a DENORMAL sigmoid -- gate pre-activations near -88 -- has an infinite v_rcp_f32 while g^2 underflows to
+                        // zero: 0 * inf = NaN; below the smallest normal number the factor is taken as 0, like an underflowed sigmoid)
+                        const float ff = sv >= 1.17549435e-38f ? sv - g_ * g_ * __builtin_amdgcn_rcpf(sv) : 0.0f;
                         qf[j][e] = dg * ff;
                         qg[j][e] = dg * g_ * (1.0f - sv);
                     } else {
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
                         qg[j][e] = dg * th[j][e] * sg[j][e] * (1.0f - sg[j][e]);
                     }
                     gmax = fmaxf(gmax, fmaxf(fabsf(qf[j][e]), fabsf(qg[j][e])));
-                    gbad |= !(fabsf(dg) <= 3.0e38f);
+                    gbad |= !(fabsf(dg) <= 3.0e38f) || !(fabsf(qf[j][e]) <= 3.0e38f) || !(fabsf(qg[j][e]) <= 3.0e38f);
                     pf[e * T + 32 * j] = qf[j][e];
                     pq[e * T + 32 * j] = qg[j][e];
                 }
@@ -1260,7 +1270,7 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(d.R >= 0 && d.R % 256 == 0 && d.S >= 0 && d.S % 256 == 0 && d.S + d.R > 0, "vqw_f16x3_out_conv: R and S must be multiples of 256 (R=%d S=%d)", d.R, d.S);
     const int cin = d.Cin > 0 ? d.Cin : d.R, xkc = d.xp_KC > 0 ? d.xp_KC : cin / 8;
     VQW_CHECK(cin >= 64 && cin % 32 == 0 && d.xp_kc0 >= 0 && d.xp_kc0 + cin / 8 <= xkc && (d.ks <= 1 || d.xp_kc0 == 0), "vqw_f16x3_out_conv: bad contraction range (Cin=%d kc0=%d KC=%d)", cin, d.xp_kc0, xkc);
-    VQW_CHECK((size_t)2 * xkc * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_out_conv: activation planes exceed 2 GiB");
+    VQW_CHECK((size_t)(cin / 8) * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_out_conv: the chunks of one contraction (Cin = %d) exceed 2 GiB per plane: cut it into channel groups", cin);
     VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_out_conv: w_scale_inv must be positive");
     OutArgs a;
     a.d = d;
@@ -1305,9 +1315,8 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_gate_conv: T must be a positive multiple of 256 (got %d)", d.T);
     VQW_CHECK(d.R > 0 && d.R % 128 == 0, "vqw_f16x3_gate_conv: R must be a multiple of 128 (got %d)", d.R);
     VQW_CHECK(d.ks >= 1 && d.ks <= 8 && d.dilation >= 1, "vqw_f16x3_gate_conv: bad kernel size %d / dilation %d", d.ks, d.dilation);
-    VQW_CHECK((size_t)2 * (d.R / 8) * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_gate_conv: activation planes exceed 2 GiB");
-    VQW_CHECK(d.out_planes_KC == 0 || (d.out_planes_kc0 >= 0 && d.out_planes_kc0 + d.R / 8 <= d.out_planes_KC &&
-                                       (size_t)2 * d.out_planes_KC * d.B * d.T * 16 < (size_t)1 << 31),
+    VQW_CHECK((size_t)(d.R / 8) * d.B * d.T * 16 < (size_t)1 << 31, "vqw_f16x3_gate_conv: one activation plane exceeds 2 GiB");
+    VQW_CHECK(d.out_planes_KC == 0 || (d.out_planes_kc0 >= 0 && d.out_planes_kc0 + d.R / 8 <= d.out_planes_KC),
               "vqw_f16x3_gate_conv: bad output plane range (kc0=%d KC=%d)", d.out_planes_kc0, d.out_planes_KC);
     VQW_CHECK(d.w_scale_inv > 0.0f, "vqw_f16x3_gate_conv: w_scale_inv must be positive");
     GateArgs a;

@@ -13,6 +13,7 @@ variable names and shapes.
 import json
 import math
 import os
+import sys
 from collections import OrderedDict
 
 import torch
@@ -122,6 +123,7 @@ class VQVAE:
         self.dgrad_f16x3 = ladder in ('4', '5')
         self.gbwd_f16x3 = ladder == '5'
         self._x3_active = True         # False while a step is being repeated on the fp32 engine
+        self._x3_warned = set()        # (B, T) shapes already reported as running on the fp32 engine
         self.x3_fallbacks = 0          # steps repeated on the fp32 engine because a plane left fp16's range
         self.x3_steps = 0              # steps that ran on the fp16x3 engine
         self._side = None
@@ -540,10 +542,24 @@ class VQVAE:
         # fp16x3 needs whole 256-step tiles inside a batch row, 128-channel blocks and one condition frame per 32 steps;
         # |w| < 255 and |net| < 65504 (fp16 range of the leading planes) are assumed, not checked
         f16x3 = self.gate_f16x3 and T % 256 == 0 and R % 128 == 0 and (T // Tz) % 32 == 0
-        f16x3_skip = f16x3 and self.skip_f16x3 and R % 256 == 0 and S % 256 == 0 and 2 * L * R * B * T * 2 < (1 << 31)
+        f16x3_skip = f16x3 and self.skip_f16x3 and R % 256 == 0 and S % 256 == 0
         f16x3_out = f16x3 and self.out_f16x3 and R % 256 == 0 and S % 256 == 0    # the 1x1 skip + residual conv too; it hands the next layer its planes
         if self.x3_all and not (f16x3_skip and self._x3_active):   # guarded / bf16 engine: all of it or none of it
+            if self._x3_active and (B, T) not in self._x3_warned:
+                self._x3_warned.add((B, T))
+                why = ('length %d is not a multiple of 256' % T if T % 256 else
+                       'residual / skip widths %d / %d are not multiples of 256' % (R, S) if (R % 256 or S % 256) else
+                       '%d samples per condition frame is not a multiple of 32' % (T // Tz))
+                print('[vqwave] batch %d x length %d runs on the fp32-MFMA engine (about half the speed of the %s engine): %s'
+                      % (B, T, 'bf16' if self.bf16 else 'fp16x3', why), file=sys.stderr, flush=True)
             f16x3 = f16x3_skip = f16x3_out = False
+        # the skip contraction over all layers reads L*R/8 chunks of the gated planes through 32-bit offsets: at most 2 GiB
+        # per plane and launch, so a large batch cuts it into groups of layers (batch 16 x 6656: 2 groups; one up to B*T = 139 k)
+        ngrp = max(1, int(os.environ.get('VQW_SKIP_GROUPS', '1')))          # (the variable forces groups at small shapes: tests)
+        while f16x3_skip and (L % ngrp or 2 * (L // ngrp) * R * B * T >= (1 << 31)):
+            ngrp += 1
+        ws['skip_groups'] = ngrp if f16x3_skip else 0
+        Lg = L // ngrp
         ws['x3_used'] = bool(f16x3_skip and self.x3_all)
         md = self.x3_mode_fwd
         gd = self.x3_guard and f16x3_skip
@@ -578,8 +594,8 @@ class VQVAE:
                         C0=R, taps=[0])                                                   # wavenet.py:53-54
         if f16x3:      # this step's weights of all layers as fp16 planes, one launch per kind
             K.f16x3_pack_gate_weights(P['gated_w'], ws['wp_all'], self.ks, R, 2 * R, WS, count=L, scale_dev=sc('WG'), mode=md)
-            if f16x3_skip:     # [L*R][S] skip kernels of all layers as one K = L*R operand; the residual kernels per layer
-                K.f16x3_pack_weights(P['out_w'], ws['wskip'], L * R, S, S + R, WS, scale_dev=sc('WO'), mode=md)
+            if f16x3_skip:     # [L*R][S] skip kernels of all layers as one K = L*R operand (per layer group); the residual kernels per layer
+                K.f16x3_pack_weights(P['out_w'], ws['wskip'], Lg * R, S, S + R, WS, count=ngrp, scale_dev=sc('WO'), mode=md)
                 K.f16x3_pack_weights(P['out_w'].view(-1)[S:], ws['wres'], R, R, S + R, WS, count=L, scale_dev=sc('WO'), mode=md)
             elif f16x3_out:
                 K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, WS, count=L, mode=md)
@@ -614,11 +630,15 @@ class VQVAE:
             K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
                         aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
                         epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['out'])                                       # :132-136, wavenet.py:72-73
+        wsk = ws['wskip'].view(ngrp, -1) if f16x3_skip else None
         if head_x3:      # the same contraction hands relu(skip) over as planes; wavenet.py:80-96 on planes
-            K.f16x3_out_conv(epi=2, xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
-                             net_in=ws['skip'], net_out=ws['skip'], net_out_planes=ws['hp'], relu_planes=True, B=B, T=T, R=S, S=0,
-                             w_scale_inv=1.0 / WS, w_scale=sc('WO'), out_scale=sc('SK'), out_amax=am('SK'), flag=flag,
-                             mode=self.x3_mode_skip)
+            for gi in range(ngrp):
+                last = gi == ngrp - 1
+                K.f16x3_out_conv(epi=2, xp=ws['gp'], Cin=Lg * R, xp_kc0=gi * Lg * (R // 8), xp_KC=L * (R // 8), wp=wsk[gi],
+                                 bias=P['out_b'][:, :S].sum(0) if gi == 0 else None, net_in=ws['skip'], net_out=ws['skip'],
+                                 net_out_planes=ws['hp'] if last else None, relu_planes=last, B=B, T=T, R=S, S=0,
+                                 w_scale_inv=1.0 / WS, w_scale=sc('WO'), out_scale=sc('SK') if last else None,
+                                 out_amax=am('SK') if last else None, flag=flag if last else None, mode=self.x3_mode_skip)
             K.f16x3_out_conv(epi=2, xp=ws['hp'], Cin=S, wp=ws['wpost1'], bias=P['post1_b'], cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz,
                              cond_bstride=cbs, net_out=ws['h1'], net_out_planes=ws['hp2'], relu_planes=True, B=B, T=T, R=S, S=0,
                              w_scale_inv=1.0, x_scale=sc('SK'), w_scale=sc('WH'), out_scale=sc('H1'), out_amax=am('H1'), flag=flag,
@@ -626,9 +646,10 @@ class VQVAE:
             K.f16x3_out_conv(epi=2, xp=ws['hp2'], Cin=S, wp=ws['wpost2'], bias=P['post2_b'], net_out=ws['logits'], B=B, T=T, R=Q,
                              S=0, w_scale_inv=1.0, x_scale=sc('H1'), w_scale=sc('WH'), mode=md)
             return
-        if f16x3_skip:   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
-            K.f16x3_out_conv(xp=ws['gp'], Cin=L * R, xp_KC=L * (R // 8), wp=ws['wskip'], bias=P['out_b'][:, :S].sum(0),
-                             skip=ws['skip'], B=B, T=T, R=0, S=S, w_scale_inv=1.0 / WS, w_scale=sc('WO'), mode=self.x3_mode_skip)
+        for gi in range(ngrp if f16x3_skip else 0):   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
+            K.f16x3_out_conv(xp=ws['gp'], Cin=Lg * R, xp_kc0=gi * Lg * (R // 8), xp_KC=L * (R // 8), wp=wsk[gi],
+                             bias=P['out_b'][:, :S].sum(0) if gi == 0 else None, skip=ws['skip'], B=B, T=T, R=0, S=S,
+                             w_scale_inv=1.0 / WS, w_scale=sc('WO'), mode=self.x3_mode_skip)
         K.conv_gemm(x0=ws['skip'], in_relu=True, w=P['post1_w'], bias=P['post1_b'], out0=ws['h1'],
                     cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T_in=T, T_out=T, M=S,
                     C0=S, taps=[0])                                                       # wavenet.py:80-88
@@ -650,6 +671,23 @@ class VQVAE:
         K.softmax_xent(ws['logits'], ws['labels'], loss_sum=self.loss_buf[0:1],
                        dlogits=ws['logits'] if compute_grad_seed else None, grad_scale=1.0 / N)  # model.py:91-94
         K.rowsum(ws['mind'].view(1, 1, -1), total=self.loss_buf[1:2])
+        return ws
+
+    def forward_checked(self, x, spk, compute_grad_seed=False):
+        """forward() for callers that do not go on to train_step (evaluation, summaries of a held-out batch).  On the guarded
+        fp16x3 engine the activation planes are scaled with the PREVIOUS training step's max-abs values (1.0 on a fresh model):
+        train_step reads the range flag and repeats a flagged step on the fp32 engine; a bare forward() does not.  This one
+        does: the flag is zeroed, read after the pass (one host sync) and a flagged pass is repeated on the fp32 engine."""
+        if not self.x3_guard:
+            return self.forward(x, spk, compute_grad_seed)
+        self.x3_flag.zero_()
+        ws = self.forward(x, spk, compute_grad_seed)
+        if (ws.get('x3_used') or ws.get('enc_x3')) and int(self.x3_flag.item()) != 0:
+            self._x3_active = False
+            try:
+                ws = self.forward(x, spk, compute_grad_seed)
+            finally:
+                self._x3_active = True
         return ws
 
     def losses(self, ws):
@@ -1063,9 +1101,9 @@ class VQVAE:
     def _x3_overflowed(self):
         """Range flag of this step (max over the data-parallel ranks: every rank must take the same branch)."""
         flag = self.x3_flag
-        if self.grad_sync is not None and self.grad_sync.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.grad_sync.group)
+        if self.grad_sync is not None and self.grad_sync.active:
+            self.x3_own_flag = int(flag.item())      # (this rank's own verdict, kept for diagnostics)
+            self.grad_sync.all_reduce_max(flag)
         return int(flag.item()) != 0
 
     # ------------------------------------------------------------------ generation
@@ -1091,11 +1129,15 @@ class VQVAE:
         self._ws.clear()
 
     def state_dict(self):
+        # x3_scale: the guarded engine's power-of-two plane scales (measured by the last step, used by the next): with them a
+        # resumed run continues exactly as the uninterrupted one would (without them its first step runs on the start-up scales)
         return {'flat': self.flat, 'ema': self.ema, 'adam_m': self.adam_m, 'adam_v': self.adam_v,
-                'bn_mean': self.bn_mean, 'bn_var': self.bn_var,
+                'bn_mean': self.bn_mean, 'bn_var': self.bn_var, 'x3_scale': self.x3_scale,
                 'global_step': torch.tensor(self.global_step, dtype=torch.int64)}
 
     def load_state_dict(self, sd):
         for k in ('flat', 'ema', 'adam_m', 'adam_v', 'bn_mean', 'bn_var'):
             getattr(self, k).copy_(sd[k].to(self.dev))
+        if 'x3_scale' in sd and tuple(sd['x3_scale'].shape) == tuple(self.x3_scale.shape):      # (absent in round-2 files)
+            self.x3_scale.copy_(sd['x3_scale'].to(self.dev))
         self.global_step = int(sd['global_step'])

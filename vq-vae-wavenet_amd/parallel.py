@@ -11,18 +11,24 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    def __init__(self, flat_grad, group=None):
+    """force=True: run every collective even in a world of one rank (a 1-rank RCCL all-reduce is an identity, but it is the
+    real communicator, bucket slices, side-stream joins and flag exchange: how a 1-GPU box exercises the N > 1 code path)."""
+
+    def __init__(self, flat_grad, group=None, force=False):
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        self.buckets = []           # (lo, hi) of every bucket exchanged since the last finish(), in launch order
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self.pending = []
 
     def bucket_ready(self, lo, hi):
         """flat[lo:hi] holds final local gradients: start summing it across ranks."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
+        self.buckets.append((lo, hi))
         view = self.flat[lo:hi]
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -33,9 +39,16 @@ class GradAllReduce:
 
     def finish(self):
         """Wait for all buckets; returns the world size (the caller scales by 1/world)."""
-        if self.cuda and self.world > 1:
+        if self.cuda and self.active:
             torch.cuda.current_stream().wait_stream(self.stream)
         for w in self.pending:
             w.wait()
         self.pending = []
+        self.last_buckets, self.buckets = self.buckets, []
         return self.world
+
+    def all_reduce_max(self, t):
+        """In-place MAX over the ranks (the fp16x3 engine's range flag: every rank must take the same branch)."""
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
