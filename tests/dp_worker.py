@@ -73,7 +73,8 @@ def rccl_one_rank(pkg, out_dir):
             return real_all_reduce(t, op=op, group=group, async_op=async_op)
         before = t.clone()                             # (on the stream the collective is queued on)
         r = real_all_reduce(t, op=op, group=group, async_op=async_op)
-        seen['identical'] = seen['identical'] and bool(torch.equal(before, t))
+        # bit patterns, not values: the first pass of this step overflows on purpose and its gradients hold NaNs
+        seen['identical'] = seen['identical'] and bool(torch.equal(before.view(torch.int32), t.view(torch.int32)))
         return r
     dist.all_reduce = checked_all_reduce
     try:

@@ -13,7 +13,8 @@ pkg = importlib.import_module('vq-vae-wavenet_amd')
 K = pkg.kernels
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 print('VQW_X3_HALF =', os.environ.get('VQW_X3_HALF', K.DEFAULT_X3_HALF))
-B, T, R, S, ks = 8, 6656, 256, 512, 3
+B, T, R, S, ks = int(os.environ.get('XB', '8')), int(os.environ.get('XT', '6656')), 256, 512, 3
+print('B, T =', B, T)
 dev = 'cuda'
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)  # noqa: E731

@@ -113,6 +113,11 @@ def conv1d_v2(net, kernel, bias=None, padding='CAUSAL', dilations=1, stride=1):
                         stride=stride, offset=-(k - 1))
         return _btc(out)
     x = _bct(net)
+    if Cin % 16:        # the conv engine contracts over channel blocks of 16: zero channels against zero kernel rows
+        pad = 16 - Cin % 16
+        x = torch.nn.functional.pad(x, (0, 0, 0, pad)).contiguous()
+        kernel = torch.nn.functional.pad(kernel, (0, 0, 0, pad))
+        Cin += pad
     To = -(-T // stride)
     y = torch.empty(B, Cout, To, device=net.device)
     L.check(L.lib().vqw_causal_conv1d_fwd(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), B, Cin, Cout,
@@ -139,8 +144,13 @@ def _condition_projection(condition, cond_kernel, C):
     """The 1x1 (no bias) of add_condition (wavenet_ops.py:97) -> [B, C, T_cond] in the kernels' layout."""
     B, Tc, Cc = condition.shape
     enc = torch.empty(B, C, Tc, device=condition.device)
-    K.conv_gemm(x0=_bct(condition), w=cond_kernel.reshape(Cc, C).contiguous(), out0=enc, B=B, T_in=Tc, T_out=Tc, M=C,
-                C0=Cc, taps=[0])
+    x, w = _bct(condition), cond_kernel.reshape(Cc, C)
+    if Cc % 16:         # the conv engine contracts over channel blocks of 16: zero channels against zero kernel rows
+        pad = 16 - Cc % 16
+        x = torch.nn.functional.pad(x, (0, 0, 0, pad))
+        w = torch.nn.functional.pad(w, (0, 0, 0, pad))
+        Cc += pad
+    K.conv_gemm(x0=x.contiguous(), w=w.contiguous(), out0=enc, B=B, T_in=Tc, T_out=Tc, M=C, C0=Cc, taps=[0])
     return enc
 
 
