@@ -69,7 +69,7 @@ class KernelTimers:
 
     def __init__(self, kernels_mod):
         self.K = kernels_mod
-        self.orig = {n: getattr(kernels_mod, n) for n in ('conv_gemm', 'f16x3_gate_conv', 'f16x3_wgrad', 'wgrad_gemm')}
+        self.orig = {n: getattr(kernels_mod, n) for n in ('conv_gemm', 'f16x3_gate_conv', 'f16x3_wgrad', 'f16x3_wgrad_batch', 'wgrad_gemm')}
         self.x3 = False          # the plane engine's gate kernel was the one launched
         self.events = {'gate': [], 'wgrad': []}
         self.on = False
@@ -104,12 +104,27 @@ class KernelTimers:
             else:
                 o['f16x3_wgrad'](**kw)
 
+        def wgrad_batch(problems, **kw):      # the weight gradients of several layers in one launch
+            if self.on:
+                fl = 0.0
+                for pr in problems:
+                    q = dict(kw, **pr)
+                    fl += 2.0 * q['B'] * q['T'] * q['Cp'] * len(q['taps']) * (q['Q0'] + q.get('Q1', 0))
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                o['f16x3_wgrad_batch'](problems, **kw)
+                e1.record()
+                self.events['wgrad'].append((e0, e1, fl))
+            else:
+                o['f16x3_wgrad_batch'](problems, **kw)
+
         def wgrad_fp32(**kw):
             if self.on:
                 self._timed('wgrad', o['wgrad_gemm'], kw, 2.0 * kw['B'] * kw['T_q'] * kw['Cp'] * len(kw['taps']) * (kw['Q0'] + kw.get('Q1', 0)))
             else:
                 o['wgrad_gemm'](**kw)
-        K.conv_gemm, K.f16x3_gate_conv, K.f16x3_wgrad, K.wgrad_gemm = conv_gemm, gate_conv, wgrad_x3, wgrad_fp32
+        K.conv_gemm, K.f16x3_gate_conv, K.f16x3_wgrad, K.wgrad_gemm, K.f16x3_wgrad_batch = conv_gemm, gate_conv, wgrad_x3, wgrad_fp32, wgrad_batch
         return self
 
     def __exit__(self, *a):

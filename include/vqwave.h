@@ -492,9 +492,14 @@ typedef struct vqw_f16x3_wgrad_desc {
                              * 2 t + tap_shift[j] (shifts of either sign; outside [0, Tp) = zero padding); fp16x3 mode only;
                              * T then only has to be a multiple of 4                                           */
     int32_t Tp;
-    int32_t xcd_group;      /* block placement: 0 = default (the taps of one tile and K range on one XCD where that fills the XCDs evenly), 1 = on, 2 = off */
+    int32_t xcd_group;      /* ignored since round 3 (the block -> XCD placement is always K range, then tile, then tap) */
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
+/* `n` (<= 32) weight gradients of ONE shape in one launch -- the same kernels of several layers: d[i] may differ in p, q0, q1, dw,
+ * the scales, q_total, q_seg and tap_shift only.  The K split is chosen for the tiles of all problems together, so the slab
+ * traffic per problem falls with n (tiles * nsplit <= CUs partial tiles per LAUNCH).  Results per problem are bit-identical
+ * for a given n (fixed summation order), not across different n (the K ranges differ).                                   */
+int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* d, int n, vqw_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -759,6 +759,58 @@ def test_gate_backward_f16x3_from_tanh_or_from_gated(K, half):
         assert (got_p - want).abs().max().item() <= 3e-6 * want.abs().max().item()
 
 
+def test_wgrad_f16x3_batch_of_layers_in_one_launch(K):
+    """vqw_f16x3_wgrad_batch: the gate-kernel gradients of five layers (different dilations, operands, scales, outputs, condition
+    sums) in ONE launch against the five single launches and fp64 samples; the residual-half form (dw a column block of a wider
+    matrix, bias sums); bitwise reproducible from run to run."""
+    B, T, R, S, Tz = 2, 2048, 256, 512, 32
+    gen = torch.Generator().manual_seed(19)
+    dils = [4, 8, 64, 256, 512]
+    nets = [torch.randn(B, R, T, generator=gen).to(DEV) for _ in dils]
+    dpres = [(torch.randn(B, 2 * R, T, generator=gen) * 1e-5).to(DEV) for _ in dils]
+    scales = torch.tensor([2.0 ** 9, 2.0 ** 10, 2.0 ** 11, 2.0 ** 10, 2.0 ** 9, 2.0 ** 27, 2.0 ** 26, 2.0 ** 27, 2.0 ** 28, 2.0 ** 27], device=DEV)
+    slab = torch.empty(256 * 65536, device=DEV)
+
+    def run(batched):
+        dws = [torch.zeros(3, R, 2 * R, device=DEV) for _ in dils]
+        segs = [torch.zeros(B, 2 * R, Tz, device=DEV) for _ in dils]
+        probs = [dict(p=nets[i], q0=dpres[i], dw=dws[i], taps=[-2 * d, -d, 0], p_scale=scales[i:i + 1], q0_scale=scales[5 + i:6 + i],
+                      q_seg=segs[i]) for i, d in enumerate(dils)]
+        common = dict(slab=slab, B=B, T=T, Cp=R, Q0=2 * R, seg_T=Tz)
+        if batched:
+            K.f16x3_wgrad_batch(probs, **common)
+        else:
+            for pr in probs:
+                K.f16x3_wgrad(**dict(common, **pr))
+        return dws, segs
+    one, seg1 = run(False)
+    bat, segb = run(True)
+    bat2, _ = run(True)
+    for i, d in enumerate(dils):
+        close(bat[i], one[i], rtol=2e-6, atol=2e-6, what='batched gate wgrad, layer %d' % i)     # other K ranges: not bit-equal
+        assert torch.equal(bat[i], bat2[i]), 'batched dW is not reproducible'
+        close(segb[i], dpres[i].view(B, 2 * R, Tz, T // Tz).sum(-1), rtol=1e-4, atol=1e-4, what='condition sums, layer %d' % i)
+        for (j, c, o) in ((0, 3, 500), (1, 255, 0), (2, 100, 257)):
+            sh = (2 - j) * d
+            w64 = (nets[i][:, c, :T - sh].double() * dpres[i][:, o, sh:].double()).sum().item()
+            assert abs(bat[i][j, c, o].item() - w64) <= 2e-6 * bat[i].abs().max().item(), (i, j, c, o)
+    # residual halves: dW_r[l] = gated[l] (x) dnet[l+1] into columns S.. of [R][S+R], bias sums of dnet
+    gated = [torch.randn(B, R, T, generator=gen).to(DEV) * 0.3 for _ in range(3)]
+    dnets = [(torch.randn(B, R, T, generator=gen) * 3e-5).to(DEV) for _ in range(3)]
+    dwo = [torch.zeros(R, S + R, device=DEV) for _ in range(3)]
+    tot = [torch.zeros(R, device=DEV) for _ in range(3)]
+    K.f16x3_wgrad_batch([dict(p=gated[i], q0=dnets[i], dw=dwo[i].view(-1)[S:], q_total=tot[i]) for i in range(3)], slab=slab, B=B, T=T,
+                        Cp=R, Q0=R, lddw=S + R, taps=[0], q0_scale=scales[6:7], total_cols=(0, R))
+    for i in range(3):
+        want = torch.einsum('bct,bot->co', gated[i].double(), dnets[i].double())
+        assert float(dwo[i][:, :S].abs().max()) == 0.0
+        assert float((dwo[i][:, S:].double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+        close(tot[i], dnets[i].sum((0, 2)), rtol=1e-4, atol=1e-7, what='bias sums')
+    with pytest.raises(RuntimeError, match='differs from problem 0'):
+        K.f16x3_wgrad_batch([dict(p=nets[0], q0=dpres[0], dw=dws, taps=t_) for dws, t_ in ((one[0], [-8, -4, 0]), (one[1][:2], [-4, 0]))],
+                            slab=slab, B=B, T=T, Cp=R, Q0=2 * R)
+
+
 def test_wgrad_f16x3_full_size_matches_fp32_engine(K):
     """The benchmark's shapes (B=8, T=6656: 1664 stage pairs over 42 / 85 K splits): gate-conv and 1x1 weight gradients
     against the fp32 engine's wgrad kernel and fp64 samples."""

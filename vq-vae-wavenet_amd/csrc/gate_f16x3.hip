@@ -892,27 +892,56 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
 // Output tile 256 (c) x 256 (o) per block; the K range B*T is cut into `nsplit` contiguous chunks per tile so that
 // tiles * nsplit fills the chip once; partial tiles go to a slab [tile][split][256][256] and a second kernel adds them
 // up in a fixed order (no atomics: dW is bitwise reproducible).  Needs T % 32 == 0, C % 256 == 0, shifts <= 0.
-struct WgArgs {
+// One launch carries up to WG_MAX_BATCH independent problems of the same shape (the weight gradients of several layers):
+// every problem has its own operands, scales, sums and output, the tiles of all problems share the K split -- the slab
+// holds tiles x splits <= CUs partial tiles whatever the batch size, so a batch of n layers writes and re-reads 1/n of
+// the slab bytes per layer that n single launches would.
+constexpr int WG_MAX_BATCH = 32;
+struct WgProblem {
     const float* p;
     const float* q0;
     const float* q1;
-    float* slab;
+    float* dw;
     const float* sp;      // device scalars (or NULL = 1): power-of-two scales of p, q0, q1
     const float* sq0;
     const float* sq1;
+    // sums of q over time, formed from the registers that hold q anyway (blocks of the problem's first row tile and tap only):
+    float* q_total;       // [Q0 + Q1] += sum_{b,t} q[b][o][t]  (bias gradients) or NULL
+    float* q_seg;         // [B][seg_bstride/..]: q_seg[b * seg_bstride + o * seg_T + t / seg_ratio] += q[b][o][t] (the transpose of
+                          //   add_condition's upsampling, wavenet_ops.py:98-100) or NULL; seg_ratio % 32 == 0
+    int shift[VQW_MAX_TAPS];
+};
+struct WgArgs {
+    WgProblem pr[WG_MAX_BATCH];
+    float* slab;
+    int nprob;
     int B, T, Cp, Q0, Q1, ntaps;
     int Tp;               // row length of p (= T, or the input length of a stride-2 conv: p index 2 t + shift)
     int p_relu;           // p := max(p, 0) on the way in (the convs behind a relu, wavenet.py:79, 93)
-    int xcd_groups;       // > 0: block -> (tile, split) by XCD-local groups of taps (see the kernel); = (tiles / ntaps) * nsplit
-    int shift[VQW_MAX_TAPS];
     int nsplit, pairs_row, pairs_total, n_nt;
-    // sums of q over time, formed from the registers that hold q anyway (blocks of the first row tile only):
-    float* q_total;       // [Q0 + Q1] += sum_{b,t} q[b][o][t]  (bias gradients) or NULL
-    float* q_seg;         // [B][seg_bstride/..]: q_seg[b * seg_bstride + o * seg_T + t / seg_ratio] += q[b][o][t] (the transpose of
-    long seg_bstride;     //   add_condition's upsampling, wavenet_ops.py:98-100) or NULL; seg_ratio % 32 == 0
+    long seg_bstride;
     int seg_T, seg_ratio;
     int total_o0, total_o1;   // q_total covers columns [total_o0, total_o1) only (e.g. the residual rows S..S+R)
+    long lddw, dw_tap_stride; // (the reduction)
 };
+// Work item w (after the XCD remap: consecutive w on one XCD) -> (K split, problem, row tile, column tile, tap), taps fastest:
+// the taps of one tile and K range read the same q panel and p panels that are the same cache lines a few elements apart, the
+// column tiles of a row tile share its p panel, and everything of one K range sits on as few XCDs (L2s) as possible.
+struct WgItem {
+    int prob, tap, rtl, nt, split, gtile;      // rtl: 256-row tile within the problem; gtile: slab / reduction index
+};
+__device__ __forceinline__ WgItem wg_decode(int w, const WgArgs& a) {
+    const int cpt = a.Cp / 256;
+    WgItem it;
+    it.tap = w % a.ntaps; w /= a.ntaps;
+    it.nt = w % a.n_nt; w /= a.n_nt;
+    const int rows_all = a.nprob * cpt, rt = w % rows_all;
+    it.split = w / rows_all;
+    it.prob = rt / cpt;
+    it.rtl = rt - it.prob * cpt;
+    it.gtile = ((it.prob * a.ntaps + it.tap) * cpt + it.rtl) * a.n_nt + it.nt;
+    return it;
+}
 
 template <bool BF>
 __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
@@ -937,34 +966,22 @@ template <bool ODD, bool BF, bool S2 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const int cpt = a.Cp / 256;                       // 256-row tiles per tap
-    int tile, split;
-    if (a.xcd_groups > 0) {
-        // consecutive block ids go round the 8 XCDs: the taps of one (row tile, column tile, K range) -- same q panel, p panels
-        // that are the same cache lines shifted by a few elements -- are given to ONE XCD (slot = id / 8 counts groups x taps)
-        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int gi = slot / a.ntaps, tp = slot - gi * a.ntaps, g = gi * 8 + x;
-        if (g >= a.xcd_groups) return;                // (whole block, before any barrier)
-        const int mn = g / a.nsplit;                  // (row tile within the tap, column tile)
-        split = g - mn * a.nsplit;
-        tile = (tp * cpt + mn / a.n_nt) * a.n_nt + mn % a.n_nt;
-    } else {
-        tile = blockIdx.x / a.nsplit;
-        split = blockIdx.x - tile * a.nsplit;
-    }
-    const int mt = tile / a.n_nt, nt = tile - mt * a.n_nt;
-    const int tap = mt / cpt, c0 = (mt - tap * cpt) * 256;
-    const int shift = a.shift[tap];
-    const int o0 = nt * 256;
+    const WgItem it = wg_decode(vqw_xcd_remap(blockIdx.x, gridDim.x), a);
+    const WgProblem& pr = a.pr[it.prob];
+    const int split = it.split, tap = it.tap, c0 = it.rtl * 256;
+    const int shift = pr.shift[tap];
+    const int o0 = it.nt * 256;
     const bool from_q1 = o0 >= a.Q0;
-    const float* qsrc = from_q1 ? a.q1 : a.q0;
+    const float* qsrc = from_q1 ? pr.q1 : pr.q0;
     const int Qs = from_q1 ? a.Q1 : a.Q0, oq = from_q1 ? o0 - a.Q0 : o0;
-    const float scp = dev_scale(a.sp), scq = dev_scale(from_q1 ? a.sq1 : a.sq0);
+    const float scp = dev_scale(pr.sp), scq = dev_scale(from_q1 ? pr.sq1 : pr.sq0);
     const float plo = a.p_relu ? 0.0f : -INFINITY;
     const int T = a.T;
     const int s_begin = (int)((long)split * a.pairs_total / a.nsplit), s_end = (int)((long)(split + 1) * a.pairs_total / a.nsplit);
-    const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(a.p, (unsigned)((size_t)a.B * a.Cp * (S2 ? a.Tp : T) * 4));
+    const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(pr.p, (unsigned)((size_t)a.B * a.Cp * (S2 ? a.Tp : T) * 4));
     const __amdgpu_buffer_rsrc_t rq = vqw_make_rsrc(qsrc, (unsigned)((size_t)a.B * Qs * T * 4));
+    float* const q_total = pr.q_total;
+    float* const q_seg = pr.q_seg;
 
     // One load instruction of a wave = 32 rows x 32 bytes (lane -> row lane/2, 16-byte half lane%2); chunk n of a
     // thread: 32-row group g = wv*2 + n/4, quarter nn = n%4 of the 128-byte line = stage nn/2 of the pair, k half nn%2.
@@ -1022,7 +1039,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         if (!BF) *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
     };
     // q sums (bias / condition gradients): the thread's two q rows (groups wv*2 and wv*2+1), its half of the 32 steps
-    const bool do_sum = mt == 0 && (a.q_seg != nullptr || (a.q_total != nullptr && o0 < a.total_o1 && o0 + 256 > a.total_o0));
+    const bool do_sum = it.rtl == 0 && tap == 0 && (q_seg != nullptr || (q_total != nullptr && o0 < a.total_o1 && o0 + 256 > a.total_o0));
     float qs_pair[2] = {0.f, 0.f}, qs_tot[2] = {0.f, 0.f};
     auto sum_one = [&](int n) {            // called with commit_one(n): rgq[n] still holds the raw fp32 values
 #ifdef VQW_ABL_WG_NOSUM
@@ -1037,10 +1054,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             const float both = qs_pair[h] + __shfl_xor(qs_pair[h], 1, 64);      // the partner lane holds the other 16 steps
             qs_tot[h] += qs_pair[h];
             qs_pair[h] = 0.f;
-            if (a.q_seg && hsel == 0) {
+            if (q_seg && hsel == 0) {
                 const int b = s / a.pairs_row, t0 = (s - b * a.pairs_row) * 32;
                 const int row = o0 + (wv * 2 + h) * 32 + rsub;
-                unsafeAtomicAdd(a.q_seg + (size_t)b * a.seg_bstride + (size_t)row * a.seg_T + t0 / a.seg_ratio, both);
+                unsafeAtomicAdd(q_seg + (size_t)b * a.seg_bstride + (size_t)row * a.seg_T + t0 / a.seg_ratio, both);
             }
         }
     };
@@ -1142,17 +1159,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             read_b(fb, 2 * it + 2);
         }
     }
-    if (do_sum && a.q_total) {
+    if (do_sum && q_total) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float both = qs_tot[h] + __shfl_xor(qs_tot[h], 1, 64);
             const int row = o0 + (wv * 2 + h) * 32 + rsub;
-            if (hsel == 0 && row >= a.total_o0 && row < a.total_o1) unsafeAtomicAdd(a.q_total + row, both);
+            if (hsel == 0 && row >= a.total_o0 && row < a.total_o1) unsafeAtomicAdd(q_total + row, both);
         }
     }
     // ---- partial tile -> slab [tile][split][256][256], rows c, columns o (32 lanes = 128 contiguous bytes)
     const float inv = __builtin_amdgcn_rcpf(scp * scq);
-    float* out = a.slab + ((size_t)tile * a.nsplit + split) * 65536;
+    float* out = a.slab + ((size_t)it.gtile * a.nsplit + split) * 65536;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1164,16 +1181,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
                     out[(32 * i + 8 * v4 + 4 * lhi + e) * 256 + 64 * wv + 32 * j + l31] = acc[i][j][v4 * 4 + e] * inv;
 }
 
-// dW[tap][c][o] += sum over splits (fixed order) of the slab tiles
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int n_nt, int cpt, int Cp,
-                                    long lddw, long dw_tap_stride) {
-    const int tile = blockIdx.y;
-    const int mt = tile / n_nt, nt = tile - mt * n_nt;
-    const int tap = mt / cpt, c0 = (mt - tap * cpt) * 256;
+// dW[tap][c][o] += sum over splits (fixed order) of the slab tiles; grid (64, tiles of all problems)
+__global__ void wgrad_reduce_kernel(const WgArgs a) {
+    const int gtile = blockIdx.y, cpt = a.Cp / 256, nsplit = a.nsplit;
+    int w = gtile;
+    const int nt = w % a.n_nt; w /= a.n_nt;
+    const int rtl = w % cpt; w /= cpt;
+    const int tap = w % a.ntaps, prob = w / a.ntaps;
     const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;     // 4 consecutive columns
     if (idx >= 65536) return;
     const int r = idx >> 8, col = idx & 255;
-    const float* sp = slab + (size_t)tile * nsplit * 65536 + idx;
+    const float* sp = a.slab + (size_t)gtile * nsplit * 65536 + idx;
     // four running sums (splits k = 0, 1, 2, 3 mod 4), combined at the end: a FIXED order, eight loads in flight per thread
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int k = 0;
@@ -1189,7 +1207,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         switch (k & 3) { case 0: s0 += v; break; case 1: s1 += v; break; case 2: s2 += v; break; default: s3 += v; }
     }
     const f32x4 sum = (s0 + s1) + (s2 + s3);
-    float* d = dw + (size_t)tap * dw_tap_stride + (size_t)(c0 + r) * lddw + nt * 256 + col;
+    float* d = a.pr[prob].dw + (size_t)tap * a.dw_tap_stride + (size_t)(rtl * 256 + r) * a.lddw + nt * 256 + col;
     f32x4 old = *reinterpret_cast<const f32x4*>(d);
     *reinterpret_cast<f32x4*>(d) = old + sum;
 }
@@ -1381,44 +1399,59 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     return 0;
 }
 
-int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
+int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(dp, "vqw_f16x3_wgrad: null descriptor");
-    const vqw_f16x3_wgrad_desc& d = *dp;
-    VQW_CHECK(d.p && d.q0 && d.dw && d.slab, "vqw_f16x3_wgrad: null operand");
+    VQW_CHECK(nprob >= 1 && nprob <= WG_MAX_BATCH, "vqw_f16x3_wgrad_batch: 1..%d problems per launch (got %d)", WG_MAX_BATCH, nprob);
+    const vqw_f16x3_wgrad_desc& d = dp[0];
+    VQW_CHECK(d.slab, "vqw_f16x3_wgrad: null operand");
     VQW_CHECK(d.B > 0 && d.T > 0 && (d.T % 32 == 0 || (d.p_stride == 2 && d.T % 4 == 0)),
               "vqw_f16x3_wgrad: T must be a positive multiple of 32 (of 4 with p_stride 2) (got %d)", d.T);
-    VQW_CHECK(d.Cp > 0 && d.Cp % 256 == 0 && d.Q0 > 0 && d.Q0 % 256 == 0 && d.Q1 >= 0 && d.Q1 % 256 == 0 && (d.Q1 == 0 || d.q1),
+    VQW_CHECK(d.Cp > 0 && d.Cp % 256 == 0 && d.Q0 > 0 && d.Q0 % 256 == 0 && d.Q1 >= 0 && d.Q1 % 256 == 0,
               "vqw_f16x3_wgrad: Cp, Q0, Q1 must be multiples of 256 (Cp=%d Q0=%d Q1=%d)", d.Cp, d.Q0, d.Q1);
     VQW_CHECK(d.ntaps >= 1 && d.ntaps <= VQW_MAX_TAPS, "vqw_f16x3_wgrad: 1..%d taps", VQW_MAX_TAPS);
     VQW_CHECK(d.p_stride == 0 || d.p_stride == 1 || d.p_stride == 2, "vqw_f16x3_wgrad: p_stride is 1 or 2 (got %d)", d.p_stride);
     const bool s2 = d.p_stride == 2;
     const int Tp = s2 ? d.Tp : d.T;
     VQW_CHECK(!s2 || (Tp > 0 && !(d.mode & 1)), "vqw_f16x3_wgrad: p_stride 2 needs Tp > 0 and the fp16x3 mode (Tp=%d mode=%d)", Tp, d.mode);
-    for (int j = 0; j < d.ntaps; ++j)
-        VQW_CHECK((s2 ? d.tap_shift[j] < (1 << 24) : d.tap_shift[j] <= 0) && d.tap_shift[j] > -(1 << 24),
-                  "vqw_f16x3_wgrad: tap shifts must be <= 0 unless p_stride is 2 (tap %d: %d)", j, d.tap_shift[j]);
     const size_t pbytes = (size_t)d.B * d.Cp * Tp * 4, qbytes = (size_t)d.B * (d.Q0 > d.Q1 ? d.Q0 : d.Q1) * d.T * 4;
     VQW_CHECK(pbytes < ((size_t)1 << 31) && qbytes < ((size_t)1 << 31), "vqw_f16x3_wgrad: operands exceed 2 GiB");
     const int lddw = d.lddw > 0 ? d.lddw : d.Q0 + d.Q1;
-    VQW_CHECK(lddw >= d.Q0 + d.Q1 && lddw % 4 == 0 && (reinterpret_cast<uintptr_t>(d.dw) & 15u) == 0, "vqw_f16x3_wgrad: dw must be 16-byte aligned, lddw a multiple of 4");
+    VQW_CHECK(lddw >= d.Q0 + d.Q1 && lddw % 4 == 0, "vqw_f16x3_wgrad: lddw must be a multiple of 4 and >= Q0 + Q1");
+    VQW_CHECK(d.mode >= 0 && d.mode <= 3, "vqw_f16x3_wgrad: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS (the latter has no effect here)");
     WgArgs a;
     memset(&a, 0, sizeof(a));
-    a.p = d.p; a.q0 = d.q0; a.q1 = d.q1; a.slab = d.slab; a.sp = d.p_scale; a.sq0 = d.q0_scale; a.sq1 = d.q1_scale;
+    bool odd = false;
+    for (int i = 0; i < nprob; ++i) {
+        const vqw_f16x3_wgrad_desc& e = dp[i];
+        // one shape per launch: only the operands, scales, sums, tap shifts and the output differ between the problems
+        VQW_CHECK(e.B == d.B && e.T == d.T && e.Cp == d.Cp && e.Q0 == d.Q0 && e.Q1 == d.Q1 && e.ntaps == d.ntaps && e.lddw == d.lddw &&
+                  e.dw_tap_stride == d.dw_tap_stride && e.seg_bstride == d.seg_bstride && e.seg_T == d.seg_T && e.total_o0 == d.total_o0 &&
+                  e.total_o1 == d.total_o1 && e.mode == d.mode && e.p_relu == d.p_relu && e.p_stride == d.p_stride && e.Tp == d.Tp &&
+                  e.slab == d.slab && (e.q_seg != nullptr) == (d.q_seg != nullptr),
+                  "vqw_f16x3_wgrad_batch: problem %d differs from problem 0 in shape or layout", i);
+        VQW_CHECK(e.p && e.q0 && e.dw && (e.Q1 == 0 || e.q1), "vqw_f16x3_wgrad: null operand (problem %d)", i);
+        VQW_CHECK((reinterpret_cast<uintptr_t>(e.dw) & 15u) == 0, "vqw_f16x3_wgrad: dw must be 16-byte aligned (problem %d)", i);
+        WgProblem& q = a.pr[i];
+        q.p = e.p; q.q0 = e.q0; q.q1 = e.q1; q.dw = e.dw; q.sp = e.p_scale; q.sq0 = e.q0_scale; q.sq1 = e.q1_scale;
+        q.q_total = e.q_total; q.q_seg = e.q_seg;
+        for (int j = 0; j < d.ntaps; ++j) {
+            VQW_CHECK((s2 ? e.tap_shift[j] < (1 << 24) : e.tap_shift[j] <= 0) && e.tap_shift[j] > -(1 << 24),
+                      "vqw_f16x3_wgrad: tap shifts must be <= 0 unless p_stride is 2 (problem %d, tap %d: %d)", i, j, e.tap_shift[j]);
+            q.shift[j] = e.tap_shift[j];
+            odd |= (e.tap_shift[j] & 3) != 0;
+        }
+    }
+    a.slab = d.slab; a.nprob = nprob;
     a.B = d.B; a.T = d.T; a.Cp = d.Cp; a.Q0 = d.Q0; a.Q1 = d.Q1; a.ntaps = d.ntaps; a.Tp = Tp; a.p_relu = d.p_relu;
-    for (int j = 0; j < d.ntaps; ++j) a.shift[j] = d.tap_shift[j];
     a.pairs_row = (d.T + 31) / 32; a.pairs_total = d.B * a.pairs_row;
     a.n_nt = (d.Q0 + d.Q1) / 256;
-    const int tiles = d.ntaps * (d.Cp / 256) * a.n_nt;
+    const int tiles = nprob * d.ntaps * (d.Cp / 256) * a.n_nt;
     int nsplit = d.nsplit > 0 ? d.nsplit : vqw_device_cus() / tiles;     // one round of blocks
-    // block id = tile * nsplit + split and consecutive ids go round the 8 XCDs: with nsplit a multiple of 8 all tiles of one K
-    // range sit on the same XCD and share their operand panels in its L2 (tools/wgrad_split_bench.py: gate conv 42 -> 40 splits
-    // 174 -> 160 us, 1x1 85 -> 80 splits 99 -> 97 us, although 16 CUs stay idle)
-    if (d.nsplit <= 0 && nsplit >= 8) nsplit &= ~7;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > a.pairs_total) nsplit = a.pairs_total;
     a.nsplit = nsplit;
-    a.q_total = d.q_total; a.q_seg = d.q_seg; a.seg_bstride = (long)d.seg_bstride; a.seg_T = d.seg_T;
+    a.seg_bstride = (long)d.seg_bstride; a.seg_T = d.seg_T;
     a.total_o0 = d.total_o0; a.total_o1 = d.total_o1 > 0 ? d.total_o1 : d.Q0 + d.Q1;
     a.seg_ratio = 1;
     if (d.q_seg) {
@@ -1426,31 +1459,21 @@ int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) {
                   "vqw_f16x3_wgrad: q_seg needs T / seg_T to be a multiple of 32 (T=%d seg_T=%d)", d.T, d.seg_T);
         a.seg_ratio = d.T / d.seg_T;
     }
+    a.lddw = lddw;
+    a.dw_tap_stride = d.dw_tap_stride > 0 ? (long)d.dw_tap_stride : (long)d.Cp * lddw;
     VQW_CHECK((size_t)tiles * nsplit * 65536 <= (size_t)d.slab_floats, "vqw_f16x3_wgrad: slab too small (%d tiles x %d splits x 65536 floats)", tiles, nsplit);
-    bool odd = false;
-    for (int j = 0; j < d.ntaps; ++j) odd |= (d.tap_shift[j] & 3) != 0;
-    VQW_CHECK(d.mode >= 0 && d.mode <= 3, "vqw_f16x3_wgrad: mode is a bit set of VQW_X3_BF16 | VQW_X3_HALF_BLOCKS (the latter has no effect here)");
     typedef void (*kfn_t)(WgArgs);
     const kfn_t ktab[4] = {wgrad_f16x3_kernel<false, false>, wgrad_f16x3_kernel<true, false>, wgrad_f16x3_kernel<false, true>,
                            wgrad_f16x3_kernel<true, true>};
     const kfn_t kfn = s2 ? wgrad_f16x3_kernel<false, false, true> : ktab[(odd ? 1 : 0) + 2 * (d.mode & 1)];
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
         return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-    // XCD-local tap groups (xcd_group 1 / 2 = forced on / off).  tools/wgrad_split_bench.py: encoder layer 1 (5 taps, stride 2)
-    // 541 -> 467 us; gate conv d=64 (40 splits) 159 -> 151 us, d=1 184 -> 187 us; with a split count that is not a multiple of 8
-    // the groups of an XCD no longer fill it evenly (42 splits: 255 us)
-    const bool grouped = d.ntaps > 1 && (d.xcd_group == 1 || (d.xcd_group == 0 && (s2 || nsplit % 8 == 0)));
-    int blocks = tiles * nsplit;
-    if (grouped) {
-        a.xcd_groups = (tiles / d.ntaps) * nsplit;
-        blocks = 8 * ((a.xcd_groups + 7) / 8) * d.ntaps;
-    }
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), NSTG * STG_BYTES, st, a);
-    const long tap_stride = d.dw_tap_stride > 0 ? (long)d.dw_tap_stride : (long)d.Cp * lddw;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(65536 / 4 / 256, tiles), dim3(256), 0, st, d.slab, d.dw, nsplit, a.n_nt, d.Cp / 256, d.Cp,
-                       (long)lddw, tap_stride);
+    hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(65536 / 4 / 256, tiles), dim3(256), 0, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_wgrad");
     return 0;
 }
+
+int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* dp, vqw_stream_t s_) { return vqw_f16x3_wgrad_batch(dp, 1, s_); }
 
 }  // extern "C"

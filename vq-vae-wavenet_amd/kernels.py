@@ -401,11 +401,9 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     L.check(L.lib().vqw_f16x3_gate_conv(C.byref(d), L.stream()))
 
 
-def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
+def _wgrad_desc(d, *, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
                 q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=None,
-                p_stride=1, T_p=None, p_relu=False, xcd_group=0):
-    """vqw_f16x3_wgrad: dw[j][c][o] += sum_{b,t} p[b][c][p_stride*t+taps[j]] * q[b][o][t] on the fp16x3 engine (slab = scratch;
-    p_stride 2: p rows are T_p long, indices outside [0, T_p) are zero padding)."""
+                p_stride=1, T_p=None, p_relu=False):
     mode = x3_mode(mode)
     T_p = T if T_p is None else T_p
     lddw = (Q0 + Q1) if lddw is None else lddw
@@ -416,8 +414,7 @@ def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None
         _need(q1, B * Q1 * T, 'q1')
     _need(dw, (len(taps) - 1) * dw_tap_stride + (Cp - 1) * lddw + Q0 + Q1, 'dw')
     _need(slab, 65536, 'slab')
-    d = L.F16x3WgradDesc()
-    d.p_stride, d.Tp, d.p_relu, d.xcd_group = p_stride, T_p, int(bool(p_relu)), xcd_group
+    d.p_stride, d.Tp, d.p_relu = p_stride, T_p, int(bool(p_relu))
     d.p, d.q0, d.q1, d.dw, d.slab = p.data_ptr(), q0.data_ptr(), (None if q1 is None else q1.data_ptr()), dw.data_ptr(), slab.data_ptr()
     d.slab_floats = slab.numel()
     d.p_scale, d.q0_scale, d.q1_scale = _slot(p_scale, 'p_scale'), _slot(q0_scale, 'q0_scale'), _slot(q1_scale, 'q1_scale')
@@ -433,7 +430,30 @@ def f16x3_wgrad(*, p, q0, dw, slab, B, T, Cp, Q0, taps, q1=None, Q1=0, lddw=None
         seg_bstride = seg_bstride or (Q0 + Q1) * seg_T
         _need(q_seg, (B - 1) * seg_bstride + (Q0 + Q1) * seg_T, 'q_seg')
         d.q_seg, d.seg_T, d.seg_bstride = q_seg.data_ptr(), seg_T, seg_bstride
+
+
+def f16x3_wgrad(**kw):
+    """vqw_f16x3_wgrad: dw[j][c][o] += sum_{b,t} p[b][c][p_stride*t+taps[j]] * q[b][o][t] on the fp16x3 engine (slab = scratch;
+    p_stride 2: p rows are T_p long, indices outside [0, T_p) are zero padding).  Arguments: _wgrad_desc."""
+    kw.pop('xcd_group', None)
+    d = L.F16x3WgradDesc()
+    _wgrad_desc(d, **kw)
     L.check(L.lib().vqw_f16x3_wgrad(C.byref(d), L.stream()))
+
+
+WGRAD_MAX_BATCH = 32
+
+
+def f16x3_wgrad_batch(problems, **common):
+    """vqw_f16x3_wgrad_batch: the weight gradients of several layers (one shape) in ONE launch.  `problems`: a list of dicts with
+    what differs per layer (p, q0, q1, dw, taps, p_scale, q0_scale, q1_scale, q_total, q_seg); `common`: everything else."""
+    n = len(problems)
+    if not 1 <= n <= WGRAD_MAX_BATCH:
+        raise ValueError('1..%d problems per launch (got %d)' % (WGRAD_MAX_BATCH, n))
+    arr = (L.F16x3WgradDesc * n)()
+    for d, pr in zip(arr, problems):
+        _wgrad_desc(d, **dict(common, **pr))
+    L.check(L.lib().vqw_f16x3_wgrad_batch(arr, n, L.stream()))
 
 
 def mfcc(x, mel, out, *, n_keep=13):

@@ -847,14 +847,63 @@ class VQVAE:
             K.f16x3_amax(dskip, am('G'))
         if wg_x3 and not head_x3:      # the weight-gradient kernels add the per-frame sums of dpre into the condition gradient
             dce[:, :L * 2 * R].zero_()
+        # Batched weight gradients (the engine's default): dpre and dnet of EVERY layer are kept (4.9 GB at B = 8 instead of
+        # rings of 2 / 3 buffers) and the weight gradients of several layers go out as ONE launch (vqw_f16x3_wgrad_batch):
+        #   * the skip halves of all layers' 1x1 kernels, dW_s[l] = gated[l] (x) dskip -- dskip is the same tensor for every
+        #     layer -- at once, before the layer loop: 60 tiles x 4 K splits instead of 30 x (2 tiles x 80 splits);
+        #   * the gate kernels of up to WG_GATE_BATCH layers (layers whose tap shifts are all multiples of 4 and the others --
+        #     dilations 1 and 2 -- in separate batches: the latter need the kernel's slower unaligned-window variant);
+        #   * the residual halves, dW_r[l] = gated[l] (x) dnet[l+1], of up to WG_RES_BATCH layers.
+        # A launch writes tiles x splits <= CUs partial 256x256 tiles to the slab whatever its batch size: per layer the slab
+        # traffic (2 x 61 MB per single launch, 7.3 GB per step) falls with the batch size, dskip is read once per XCD instead
+        # of once per layer, and 68 reductions become ~10.
+        batched = bool(wg_x3) and os.environ.get('VQW_WGRAD_BATCH', '1') != '0'
+        if batched and 'dpre_all' not in ws:
+            ws['dpre_all'] = [A.empty(B, 2 * R, T, device=self.dev) for _ in range(L)]
+            ws['dnet_all'] = [A.empty(B, R, T, device=self.dev) for _ in range(L)]       # dnet_all[l] = d loss / d net[l]
+            ws['_poison'] += ws['dpre_all'] + ws['dnet_all']
+        gate_batch = int(os.environ.get('VQW_WG_GATE_BATCH', '8'))
+        res_batch = int(os.environ.get('VQW_WG_RES_BATCH', '15'))
+        pend_gate, pend_res = {False: [], True: []}, []
+
+        def on_side(launch):           # weight gradients: nothing downstream waits for them
+            if side is main:
+                return launch()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                launch()
+
+        def flush_gate(odd):
+            layers, pend_gate[odd] = pend_gate[odd], []
+            if layers:
+                probs = [dict(p=net[i], q0=ws['dpre_all'][i], dw=G['gated_w'][i], taps=[-(ks - 1 - j) * self.dil[i] for j in range(ks)],
+                              p_scale=sc('X', i), q0_scale=sc('DP', i), q_seg=dce.view(-1)[i * 2 * R * Tz:]) for i in layers]
+                on_side(lambda: K.f16x3_wgrad_batch(probs, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=2 * R, seg_T=Tz, seg_bstride=cbs, mode=md))
+
+        def flush_res():
+            nonlocal pend_res
+            layers, pend_res = pend_res, []
+            if layers:         # (the top layer has no dnet: its residual kernel gets no gradient)
+                probs = [dict(p=ws['gated'][i], q0=ws['dnet_all'][i + 1], dw=G['out_w'][i].view(-1)[S:], q_total=G['out_b'][i][S:])
+                         for i in layers]
+                on_side(lambda: K.f16x3_wgrad_batch(probs, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=R, lddw=S + R, taps=[0],
+                                                    q0_scale=sc('G'), total_cols=(0, R), mode=md))
+
+        if batched:      # the skip halves of all layers
+            for i0 in range(0, L, K.WGRAD_MAX_BATCH):
+                probs = [dict(p=ws['gated'][i], dw=G['out_w'][i].view(-1)) for i in range(i0, min(L, i0 + K.WGRAD_MAX_BATCH))]
+                on_side(lambda: K.f16x3_wgrad_batch(probs, q0=dskip, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=S, lddw=S + R, taps=[0],
+                                                    q0_scale=sc('G'), mode=md))
         side_done = {}
         dnet = dnet_ring[(L - 1) % 3]
         for l in range(L - 1, -1, -1):
             d = self.dil[l]
             top = (l == L - 1)       # net[L] is unused by the graph: its gradient is zero
-            dpre = dpre_ring[l % 2]
-            dnet_next = dnet_ring[(l - 1) % 3]
-            if side is not main and (l + 2) in side_done:
+            dpre = ws['dpre_all'][l] if batched else dpre_ring[l % 2]
+            dnet_next = ws['dnet_all'][l] if batched else dnet_ring[(l - 1) % 3]
+            if not batched and side is not main and (l + 2) in side_done:
                 main.wait_event(side_done[l + 2])            # dpre[l % 2] and dnet[(l - 1) % 3] are free again
             if gbwd_x3:
                 K.f16x3_out_conv(epi=1, xp=ws['gr'], Cin=S if top else S + R, xp_KC=(S + R) // 8,
@@ -889,6 +938,17 @@ class VQVAE:
                             M=R, M0=0, C0=2 * R, taps=taps_b, epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['dgrad'])
             if calib:
                 K.f16x3_amax(dnet_next, am('G'))
+            if batched:
+                odd = any(((ks - 1 - j) * d) % 4 for j in range(ks))
+                pend_gate[odd].append(l)
+                if len(pend_gate[odd]) >= gate_batch:
+                    flush_gate(odd)
+                if not top:                  # layer l + 1 wrote dnet[l + 1] in the iteration before this one
+                    pend_res.append(l)
+                    if len(pend_res) >= res_batch:
+                        flush_res()
+                dnet = dnet_next
+                continue
             with torch.cuda.stream(side):
                 if side is not main:
                     side.wait_event(ready)
@@ -913,6 +973,10 @@ class VQVAE:
                     side_done[l] = torch.cuda.Event()
                     side_done[l].record(side)
             dnet = dnet_next
+        if batched:
+            flush_gate(False)
+            flush_gate(True)
+            flush_res()
         if side is not main:
             main.wait_stream(side)
         if wg_x3:      # gated biases: the condition gradient summed over batch and frames, all layers in one launch
