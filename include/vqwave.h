@@ -285,6 +285,9 @@ typedef struct vqw_ar_weights {
 typedef struct vqw_ar_decoder vqw_ar_decoder;
 
 int vqw_ar_decode_create(vqw_ar_decoder** out, const vqw_ar_weights* w, int batch);
+/* The same with the persistent kernel's decomposition chosen by the caller: channels_per_workgroup 4 (R/4 workgroups: the
+ * fastest single handle) or 8 (R/8 workgroups: 8 handles x 32 workgroups hold a 256-CU chip, one handle per XCD), 0 = auto. */
+int vqw_ar_decode_create_ex(vqw_ar_decoder** out, const vqw_ar_weights* w, int batch, int channels_per_workgroup);
 /* zero the queues (generate.py:105 sess.run(init_ops)) and restart at sample 0 */
 int vqw_ar_decode_reset(vqw_ar_decoder* h, vqw_stream_t s);
 /* Generate `n_steps` samples.  encoding [B][Cc][Tz] (model.encoding, channel-major);
@@ -304,8 +307,8 @@ int vqw_ar_decode_run_async(vqw_ar_decoder* h, const float* encoding, int Tz, in
                             int n_steps, int mode, const float* uniforms, float* audio,
                             int32_t* indices, float* probs_last, vqw_stream_t s);
 int vqw_ar_decode_wait(vqw_ar_decoder* h);
-/* Up to 4 handles (independent batch slices: rows never interact, generate.py:40,103-113) in ONE persistent launch,
- * grid = (workgroups, n): they generate side by side whatever hardware queues the runtime maps streams to (two
+/* Up to 8 handles (independent batch slices: rows never interact, generate.py:40,103-113) in ONE persistent launch
+ * (workgroup g works for handle g % n: with n = 8 every handle sits on one XCD): they generate side by side whatever hardware queues the runtime maps streams to (two
  * _run_async calls on two streams overlap only when those streams land on different queues).  Every handle must be on
  * the persistent kernel with the same instantiation (vqw_ar_decode_workgroups > 0, equal batch class) and
  * n * workgroups must not exceed the CU count (one resident workgroup per CU); per-handle pointer arrays, `uniforms`,

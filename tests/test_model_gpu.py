@@ -456,7 +456,9 @@ def test_fast_generation_reference_width(pkg):
 
 def test_fast_generation_batch_split(pkg):
     """Batches above 4 rows run as several persistent handles side by side (rows never interact,
-    generate.py:40): every row of a 6-row run equals the same row generated in a 2-row run, bit for bit."""
+    generate.py:40): every row of a 6-row run (six one-row handles in ONE launch, workgroup g on handle g % 6:
+    generator.pick_layout) equals the same row generated in a 2-row run, bit for bit; and so does a run forced back to
+    handles of three rows."""
     m, w = tiny_cfg()
     P = M.init_params(m, w, 10, seed=11, randomize_all=True)
     model = build(pkg, m, w, 10, P)
@@ -464,9 +466,18 @@ def test_fast_generation_batch_split(pkg):
     enc = model.encode(x[:, :, 0].contiguous().cuda(), spk.cuda())
     u = torch.rand(6, 96, generator=torch.Generator().manual_seed(1)).cuda()
     big = pkg.generator.FastGenerator(model, batch=6)
-    assert len(big._parts) == 2 and sum(big._parts) == 6
+    assert big._parts == [1] * 6 and big._waves == [list(range(6))]
     ab, ib = big.generate(enc, 96, mode='sample', uniforms=u)
     big.close()
+    os.environ['VQW_AR_ROWS'] = '3'
+    try:
+        three = pkg.generator.FastGenerator(model, batch=6)
+    finally:
+        del os.environ['VQW_AR_ROWS']
+    assert three._parts == [3, 3]
+    a3, i3 = three.generate(enc, 96, mode='sample', uniforms=u)
+    three.close()
+    assert torch.equal(i3, ib) and torch.equal(a3, ab)
     for r0 in (0, 2, 4):
         small = pkg.generator.FastGenerator(model, batch=2)
         a_s, i_s = small.generate(enc[r0:r0 + 2].contiguous(), 96, mode='sample', uniforms=u[r0:r0 + 2].contiguous())

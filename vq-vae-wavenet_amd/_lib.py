@@ -133,6 +133,7 @@ SIGNATURES = {
     'vqw_softmax_xent_bwd': (_i, [_fp, _fp, _fp, _f, _i, _i, _i, _fp]),
     'vqw_adam_ema_step': (_i, [_fp, _fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _f, _fp]),
     'vqw_ar_decode_create': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i]),
+    'vqw_ar_decode_create_ex': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i, _i]),
     'vqw_ar_decode_reset': (_i, [_fp, _fp]),
     'vqw_ar_decode_run': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
     'vqw_ar_decode_run_async': (_i, [_fp, _fp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),

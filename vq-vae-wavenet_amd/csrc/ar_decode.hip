@@ -403,7 +403,13 @@ void free_all(vqw_ar_decoder* h) {
 }  // namespace
 
 extern "C" int vqw_ar_decode_create(vqw_ar_decoder** out, const vqw_ar_weights* w, int batch) {
+    return vqw_ar_decode_create_ex(out, w, batch, 0);
+}
+
+extern "C" int vqw_ar_decode_create_ex(vqw_ar_decoder** out, const vqw_ar_weights* w, int batch, int channels_per_workgroup) {
     VQW_CHECK(out && w, "vqw_ar_decode_create: null pointer");
+    VQW_CHECK(channels_per_workgroup == 0 || channels_per_workgroup == 4 || channels_per_workgroup == 8,
+              "vqw_ar_decode_create_ex: channels_per_workgroup is 0 (auto), 4 or 8 (got %d)", channels_per_workgroup);
     VQW_CHECK(batch >= 1 && batch <= MAXB, "vqw_ar_decode_create: batch=%d must be in 1..%d", batch, MAXB);
     VQW_CHECK(w->n_layers >= 1 && w->kernel_size >= 2 && w->kernel_size <= VQW_MAX_TAPS, "vqw_ar_decode_create: bad layer config");
     VQW_CHECK(w->R % 16 == 0 && w->S % 16 == 0 && w->Q % 4 == 0 && w->Cc % 16 == 0, "vqw_ar_decode_create: R,S,Cc must be multiples of 16, Q of 4");
@@ -449,7 +455,7 @@ extern "C" int vqw_ar_decode_create(vqw_ar_decoder** out, const vqw_ar_weights* 
     }
     if (arp_supported(w, batch)) {
         const int rc = arp_create(&h->persist, w, h->dil.data(), h->gated_w.data(), h->gated_b.data(), h->out_w.data(),
-                                  h->out_b.data(), batch);
+                                  h->out_b.data(), batch, channels_per_workgroup);
         if (rc) { free_all(h); return rc; }
     }
     *out = h;
@@ -595,7 +601,7 @@ extern "C" int vqw_ar_decode_run_group_async(vqw_ar_decoder* const* hs, int n, c
                                              int ratio, int n_steps, int mode, const float* const* uniforms,
                                              float* const* audio, int32_t* const* indices,
                                              float* const* probs_last, vqw_stream_t s) {
-    VQW_CHECK(hs && encoding && audio && n >= 1 && n <= 4, "vqw_ar_decode_run_group: null pointer or n=%d outside 1..4", n);
+    VQW_CHECK(hs && encoding && audio && n >= 1 && n <= 8, "vqw_ar_decode_run_group: null pointer or n=%d outside 1..8", n);
     VQW_CHECK(Tz > 0 && ratio > 0 && n_steps > 0, "vqw_ar_decode_run: bad Tz/ratio/n_steps");
     VQW_CHECK(mode == 0 || (mode == 1 && uniforms), "vqw_ar_decode_run: mode must be 0 (greedy) or 1 (sample, needs uniforms)");
     for (int i = 0; i < n; ++i) {
@@ -613,8 +619,8 @@ extern "C" int vqw_ar_decode_run_group_async(vqw_ar_decoder* const* hs, int n, c
     hipStream_t st = hs[0]->stream;
     HIPC(hipEventRecord(hs[0]->ev_in, (hipStream_t)s));
     HIPC(hipStreamWaitEvent(st, hs[0]->ev_in, 0));
-    ArPersist* ps[4];
-    const float* const* conds[4];
+    ArPersist* ps[8];
+    const float* const* conds[8];
     for (int i = 0; i < n; ++i) {
         const int rc = project_condition(hs[i], encoding[i], Tz, st);
         if (rc) return rc;

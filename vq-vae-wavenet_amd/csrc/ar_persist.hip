@@ -83,9 +83,14 @@ struct PArgs {
 // workgroup (x, y) works on handle y.  ONE launch, because two persistent kernels on two streams only overlap when the
 // runtime happens to map the streams to different hardware queues (it did not in bench.py once a third stream existed:
 // 255 instead of 134 us per step for 8 utterances).
-constexpr int PGROUP = 4;
+// Placement (round 3): the grid is one-dimensional and workgroup g works for handle g % n as its workgroup g / n.  Consecutive
+// workgroup ids go round the 8 XCDs (each with its own L2), so handle y's workgroups sit on the XCDs = y (mod n): with n = 8
+// every handle lives on ONE XCD and all of its exchanges stay inside one L2; with n = 4 on two, with n = 1 on all eight (as
+// before).  8 handles x 32 workgroups (8 channels each) hold all 256 CUs.
+constexpr int PGROUP = 8;
 struct PGroup {
     PArgs h[PGROUP];
+    int n;
 };
 
 // LDS carve (in floats), shared by the host (size) and the device (offsets)
@@ -327,7 +332,8 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
 // vmcnt(0) in front of the first use, i.e. waits for the loads it has requested a moment earlier.)
 template <int TB, int RLT, int NS, int KS, int CPB>
 __global__ __launch_bounds__(NTHR, 1) void ar_persist_kernel(const PGroup grp) {
-    const PArgs& a = grp.h[blockIdx.y];
+    const int nhandles = grp.n;
+    const PArgs& a = grp.h[blockIdx.x % nhandles];
     extern __shared__ float lds[];
     constexpr int LPC = NCT / CPB;                        // lanes per channel
     constexpr int PUBL = LPC - 1;                         // the lane that ends up with a channel's sums and publishes them
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(NTHR, 1) void ar_persist_kernel(const PGroup grp) {
     constexpr int NCOL = 5 + NS;                          // critical columns per weight row: Wg f,g | M f,g | Wr | Ws..
     constexpr int NPW = ((KS - 1) * RLT * 2 + 3) / 4;     // float4 groups per thread: past taps
     constexpr int NCW = (RLT * NCOL + 3) / 4;             // float4 groups per thread: critical columns
-    const int bi = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
+    const int bi = blockIdx.x / nhandles, tid = threadIdx.x, nwg = gridDim.x / nhandles;
     const int role = tid < NCT ? 0 : (tid < NCT + NGF ? 1 : 2);   // 0 compute, 1 fresh, 2 history
     const int ct = tid & (NCT - 1);
     const int cg = ct / LPC, kl = ct % LPC;
@@ -830,10 +836,11 @@ __global__ void pack_head_bias_kernel(const float* __restrict__ src, int R, int 
 
 // channels per workgroup: 4 (a whole wave per channel, R/4 workgroups: half the weight stream per CU and half the
 // dot-product length per lane) where R allows it and the chip has the CUs, else 8; VQW_AR_CPB overrides
-int pick_cpb(int R, int cus) {
+int pick_cpb(int R, int cus, int want = 0) {
     int cpb = (R % 64 == 0 && R / 4 <= cus) ? 4 : 8;
     const char* env = getenv("VQW_AR_CPB");
-    if (env && (env[0] == '4' || env[0] == '8')) cpb = env[0] - '0';
+    if (want == 4 || want == 8) cpb = want;
+    else if (env && (env[0] == '4' || env[0] == '8')) cpb = env[0] - '0';
     if (cpb == 4 && R % 64) cpb = 8;
     return cpb;
 }
@@ -900,13 +907,13 @@ bool arp_supported(const vqw_ar_weights* w, int batch) {
 }
 
 int arp_create(ArPersist** out, const vqw_ar_weights* w, const int* dil, const float* const* gated_w,
-               const float* const* gated_b, const float* const* out_w, const float* const* out_b, int batch) {
+               const float* const* gated_b, const float* const* out_w, const float* const* out_b, int batch, int cpb_want) {
     ArPersist* h = new ArPersist();
     h->w = *w;
     h->B = batch;
     const int L = w->n_layers, R = w->R, S = w->S, Q = w->Q, ks = w->kernel_size;
     const int nS = S / R, nQ = Q / R;
-    int CPB = pick_cpb(R, device_cus());
+    int CPB = pick_cpb(R, device_cus(), cpb_want);
     if (!pick_kernel<1>(R, nS, ks, CPB)) CPB = 8;
     const int RL = R / (NCT / CPB), nwg = R / CPB;
     h->nS = nS; h->nQ = nQ; h->nwg = nwg; h->cpb = CPB;
@@ -1013,6 +1020,7 @@ int arp_run(ArPersist* const* hs, int n, const float* const* const* condenc, int
                              n, hs[0]->nwg, cus);
     PGroup g;
     memset(&g, 0, sizeof(g));
+    g.n = n;
     for (int i = 0; i < n; ++i) {
         ArPersist* h = hs[i];
         if (!arp_same_launch(hs[0], h)) return vqw_set_error("vqw_ar_decode_run: handles of one launch must share one kernel");
@@ -1030,7 +1038,7 @@ int arp_run(ArPersist* const* hs, int n, const float* const* const* condenc, int
         g.h[i] = a;
     }
     void* params[] = {&g};
-    PHIPC(hipLaunchKernel(hs[0]->kfn, dim3(hs[0]->nwg, n), dim3(NTHR), params, hs[0]->lds_bytes, st));
+    PHIPC(hipLaunchKernel(hs[0]->kfn, dim3(hs[0]->nwg * n), dim3(NTHR), params, hs[0]->lds_bytes, st));
     return 0;
 }
 

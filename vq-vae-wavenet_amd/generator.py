@@ -9,22 +9,46 @@ from . import _lib as L
 
 
 MAX_ROWS = 4    # batch rows of one persistent handle (its LDS budget); larger batches run as several handles
-MAX_GROUP = 4   # handles of one launch (vqw_ar_decode_run_group_async)
+MAX_GROUP = 8   # handles of one launch (vqw_ar_decode_run_group_async)
 CU_MARGIN = 8   # CUs left free when handles share a launch: a workgroup of a persistent grid that finds no free CU
-#                 keeps its siblings spinning until their timeout
+#                 keeps its siblings spinning until their timeout (not applied to the whole-chip layout below, which is
+#                 chosen only when it fits exactly and is what BASELINE.json configs[3] on one GPU asks for)
+
+
+def pick_layout(batch, R, cus):
+    """(rows per handle, channels per workgroup [0 = the library's choice]) of a batch.  Rows never interact
+    (generate.py:40,103-113), so how they are grouped into handles is free:
+      * up to MAX_ROWS rows: one handle (R/4 workgroups where the chip has them: the fastest single pipeline);
+      * 5..8 rows on a chip with 8 * R/8 CUs: ONE ROW PER HANDLE, 8 channels per workgroup -- R/8 = 32 workgroups per
+        handle, and the launch places workgroup g on handle g % n, so with 8 handles every utterance runs on its own XCD
+        (32 CUs, one L2) and the eight pipelines are independent;
+      * otherwise handles of up to MAX_ROWS rows, as many per launch as fit.
+    VQW_AR_ROWS / VQW_AR_CPB override (measurements: tools/ar_layouts.py)."""
+    import os
+    rows = cpb = None
+    if os.environ.get('VQW_AR_ROWS'):
+        rows = max(1, min(MAX_ROWS, int(os.environ['VQW_AR_ROWS'])))
+    if os.environ.get('VQW_AR_CPB') in ('4', '8'):
+        cpb = int(os.environ['VQW_AR_CPB'])
+    if rows is None and cpb is None and MAX_ROWS < batch <= MAX_GROUP and R % 8 == 0 and (R // 8) * batch <= cus:
+        return 1, 8
+    if rows is None:
+        n_parts = -(-batch // MAX_ROWS)
+        rows = -(-batch // n_parts)
+    return rows, (cpb or 0)
 
 
 class FastGenerator:
     def __init__(self, model, batch):
         """Uses the model's LIVE variables (call model.use_ema_weights() first to mirror
         generate.py:88-90, which restores the EMA shadows).  Rows of the batch never interact
-        (generate.py:40,103-113), so a batch above MAX_ROWS is cut into independent handles; as many of them as the
+        (generate.py:40,103-113), so a batch is cut into independent handles (pick_layout); as many of them as the
         chip has CUs for (one resident workgroup per CU, R/4 or R/8 workgroups per handle) share ONE launch and
         generate side by side, the rest follow in further waves."""
         self.model, self.B = model, batch
-        n_parts = -(-batch // MAX_ROWS)
-        base, extra = divmod(batch, n_parts)
-        self._parts = [base + (1 if i < extra else 0) for i in range(n_parts)]
+        cus = torch.cuda.get_device_properties(model.dev).multi_processor_count
+        rows, cpb = pick_layout(batch, model.R, cus)
+        self._parts = [rows] * (batch // rows) + ([batch % rows] if batch % rows else [])
         P = model.P
         nl, R, S = model.L, model.R, model.S
         w = L.ArWeights()
@@ -52,17 +76,18 @@ class FastGenerator:
         self._hs = []
         for nb in self._parts:
             h = C.c_void_p()
-            L.check(L.lib().vqw_ar_decode_create(C.byref(h), C.byref(w), nb))
+            L.check(L.lib().vqw_ar_decode_create_ex(C.byref(h), C.byref(w), nb, cpb))
             self._hs.append(h)
         # waves of handles that are co-resident by construction: floor((CUs - margin) / workgroups), at most MAX_GROUP
+        # (no margin where the whole batch fits the chip exactly: the one-utterance-per-XCD layout)
         nwg = [L.lib().vqw_ar_decode_workgroups(h) for h in self._hs]
-        cus = torch.cuda.get_device_properties(model.dev).multi_processor_count
+        whole = len(set(nwg)) == 1 and nwg[0] > 0 and len(self._hs) <= MAX_GROUP and nwg[0] * len(self._hs) <= cus
         self._waves, i = [], 0
         while i < len(self._hs):
             if nwg[i] <= 0:                      # launch-per-phase path: one handle at a time
                 self._waves.append([i]); i += 1
                 continue
-            cap = max(1, min(MAX_GROUP, (cus - CU_MARGIN) // nwg[i]))
+            cap = max(1, min(MAX_GROUP, (cus - (0 if whole else CU_MARGIN)) // nwg[i]))
             j = i + 1
             while j < len(self._hs) and j - i < cap and nwg[j] == nwg[i] and (self._parts[j] > 1) == (self._parts[i] > 1):
                 j += 1

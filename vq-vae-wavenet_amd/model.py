@@ -851,9 +851,9 @@ class VQVAE:
         # rings of 2 / 3 buffers) and the weight gradients of several layers go out as ONE launch (vqw_f16x3_wgrad_batch):
         #   * the skip halves of all layers' 1x1 kernels, dW_s[l] = gated[l] (x) dskip -- dskip is the same tensor for every
         #     layer -- at once, before the layer loop: 60 tiles x 4 K splits instead of 30 x (2 tiles x 80 splits);
-        #   * the gate kernels of up to WG_GATE_BATCH layers (layers whose tap shifts are all multiples of 4 and the others --
+        #   * the gate kernels of up to 6 layers (VQW_WG_GATE_BATCH) (layers whose tap shifts are all multiples of 4 and the others --
         #     dilations 1 and 2 -- in separate batches: the latter need the kernel's slower unaligned-window variant);
-        #   * the residual halves, dW_r[l] = gated[l] (x) dnet[l+1], of up to WG_RES_BATCH layers.
+        #   * the residual halves, dW_r[l] = gated[l] (x) dnet[l+1], of up to 29 layers (VQW_WG_RES_BATCH).
         # A launch writes tiles x splits <= CUs partial 256x256 tiles to the slab whatever its batch size: per layer the slab
         # traffic (2 x 61 MB per single launch, 7.3 GB per step) falls with the batch size, dskip is read once per XCD instead
         # of once per layer, and 68 reductions become ~10.
@@ -862,8 +862,8 @@ class VQVAE:
             ws['dpre_all'] = [A.empty(B, 2 * R, T, device=self.dev) for _ in range(L)]
             ws['dnet_all'] = [A.empty(B, R, T, device=self.dev) for _ in range(L)]       # dnet_all[l] = d loss / d net[l]
             ws['_poison'] += ws['dpre_all'] + ws['dnet_all']
-        gate_batch = int(os.environ.get('VQW_WG_GATE_BATCH', '8'))
-        res_batch = int(os.environ.get('VQW_WG_RES_BATCH', '15'))
+        gate_batch = int(os.environ.get('VQW_WG_GATE_BATCH', '6'))      # 36 tiles x 7 K splits = 252 blocks (tools/wg_batch_sweep.sh)
+        res_batch = int(os.environ.get('VQW_WG_RES_BATCH', '29'))
         pend_gate, pend_res = {False: [], True: []}, []
 
         def on_side(launch):           # weight gradients: nothing downstream waits for them
