@@ -456,8 +456,7 @@ def test_fast_generation_reference_width(pkg):
 
 def test_fast_generation_batch_split(pkg):
     """Batches above 4 rows run as several persistent handles side by side (rows never interact,
-    generate.py:40): every row of a 6-row run (six one-row handles in ONE launch, workgroup g on handle g % 6:
-    generator.pick_layout) equals the same row generated in a 2-row run, bit for bit; and so does a run forced back to
+    generate.py:40): every row of a 6-row run (six one-row handles in ONE launch: generator.pick_layout) equals the same row generated in a 2-row run, bit for bit; and so does a run forced back to
     handles of three rows."""
     m, w = tiny_cfg()
     P = M.init_params(m, w, 10, seed=11, randomize_all=True)

@@ -20,7 +20,8 @@ m, w = bench.default_configs()
 model = pkg.model.VQVAE(m, w, 109, device='cuda', seed=0)
 x, spk = bench.synthetic_batch(8, 6656, 109, 1234, 'cuda')
 enc8 = model.encode(x, spk)
-for batch, rows, cpb in ((1, 1, 4), (1, 1, 8), (2, 2, 4), (2, 1, 4), (2, 1, 8), (4, 4, 4), (4, 2, 4), (4, 1, 4), (4, 1, 8),
+print('VQW_AR_PLACE =', os.environ.get('VQW_AR_PLACE', 'channel'))
+for batch, rows, cpb in ((1, 1, 4), (2, 1, 4), (2, 1, 8), (4, 2, 4), (4, 1, 4), (4, 1, 8),
                          (8, 4, 4), (8, 2, 4), (8, 2, 8), (8, 1, 8), (8, None, None)):
     for k in ('VQW_AR_ROWS', 'VQW_AR_CPB'):
         os.environ.pop(k, None)

@@ -83,14 +83,19 @@ struct PArgs {
 // workgroup (x, y) works on handle y.  ONE launch, because two persistent kernels on two streams only overlap when the
 // runtime happens to map the streams to different hardware queues (it did not in bench.py once a third stream existed:
 // 255 instead of 134 us per step for 8 utterances).
-// Placement (round 3): the grid is one-dimensional and workgroup g works for handle g % n as its workgroup g / n.  Consecutive
-// workgroup ids go round the 8 XCDs (each with its own L2), so handle y's workgroups sit on the XCDs = y (mod n): with n = 8
-// every handle lives on ONE XCD and all of its exchanges stay inside one L2; with n = 4 on two, with n = 1 on all eight (as
-// before).  8 handles x 32 workgroups (8 channels each) hold all 256 CUs.
+// Placement: the grid is one-dimensional, consecutive workgroup ids go round the 8 XCDs (each with its own L2).  Default
+// ("channel"): workgroup g works for handle g / nwg as its workgroup g % nwg -- the workgroups that own the SAME channels of all
+// handles share an XCD.  VQW_AR_PLACE=handle: workgroup g works for handle g % n, i.e. with 8 handles x 32 workgroups every
+// handle lives on ONE XCD.  Measured (round 3, tools/ar_layouts.py, 8 one-row handles x 32 workgroups = all 256 CUs):
+// channel 117.7 us per step, handle 123.0 -- the exchanges are agent-scope (sc1) granules that cross the fabric wherever
+// the two workgroups sit (per-XCD L2s are not coherent: there is no correct XCD-local form), so a handle gains nothing from
+// having its workgroups on one XCD, while same-channel workgroups on one XCD read their weights through one L2.
 constexpr int PGROUP = 8;
 struct PGroup {
     PArgs h[PGROUP];
     int n;
+    int by_handle;     // 1: workgroup g works for handle g % n (a handle's workgroups share XCDs); 0: for handle g / nwg (the
+                       // workgroups with the SAME channels of all handles share an XCD, i.e. one L2 copy of their weights)
 };
 
 // LDS carve (in floats), shared by the host (size) and the device (offsets)
@@ -332,8 +337,8 @@ __device__ __forceinline__ void decode_rows(const PArgs& a, int bi, int tid, int
 // vmcnt(0) in front of the first use, i.e. waits for the loads it has requested a moment earlier.)
 template <int TB, int RLT, int NS, int KS, int CPB>
 __global__ __launch_bounds__(NTHR, 1) void ar_persist_kernel(const PGroup grp) {
-    const int nhandles = grp.n;
-    const PArgs& a = grp.h[blockIdx.x % nhandles];
+    const int nhandles = grp.n, nwg = gridDim.x / nhandles;
+    const PArgs& a = grp.h[grp.by_handle ? blockIdx.x % nhandles : blockIdx.x / nwg];
     extern __shared__ float lds[];
     constexpr int LPC = NCT / CPB;                        // lanes per channel
     constexpr int PUBL = LPC - 1;                         // the lane that ends up with a channel's sums and publishes them
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(NTHR, 1) void ar_persist_kernel(const PGroup grp) {
     constexpr int NCOL = 5 + NS;                          // critical columns per weight row: Wg f,g | M f,g | Wr | Ws..
     constexpr int NPW = ((KS - 1) * RLT * 2 + 3) / 4;     // float4 groups per thread: past taps
     constexpr int NCW = (RLT * NCOL + 3) / 4;             // float4 groups per thread: critical columns
-    const int bi = blockIdx.x / nhandles, tid = threadIdx.x, nwg = gridDim.x / nhandles;
+    const int bi = grp.by_handle ? blockIdx.x / nhandles : blockIdx.x % nwg, tid = threadIdx.x;
     const int role = tid < NCT ? 0 : (tid < NCT + NGF ? 1 : 2);   // 0 compute, 1 fresh, 2 history
     const int ct = tid & (NCT - 1);
     const int cg = ct / LPC, kl = ct % LPC;
@@ -1021,6 +1026,10 @@ int arp_run(ArPersist* const* hs, int n, const float* const* const* condenc, int
     PGroup g;
     memset(&g, 0, sizeof(g));
     g.n = n;
+    {
+        const char* env = getenv("VQW_AR_PLACE");      // "handle" / "channel" (measurements: tools/ar_layouts.py)
+        g.by_handle = (env && env[0] == 'h') ? 1 : 0;
+    }
     for (int i = 0; i < n; ++i) {
         ArPersist* h = hs[i];
         if (!arp_same_launch(hs[0], h)) return vqw_set_error("vqw_ar_decode_run: handles of one launch must share one kernel");

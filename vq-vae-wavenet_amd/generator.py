@@ -17,20 +17,26 @@ CU_MARGIN = 8   # CUs left free when handles share a launch: a workgroup of a pe
 
 def pick_layout(batch, R, cus):
     """(rows per handle, channels per workgroup [0 = the library's choice]) of a batch.  Rows never interact
-    (generate.py:40,103-113), so how they are grouped into handles is free:
-      * up to MAX_ROWS rows: one handle (R/4 workgroups where the chip has them: the fastest single pipeline);
-      * 5..8 rows on a chip with 8 * R/8 CUs: ONE ROW PER HANDLE, 8 channels per workgroup -- R/8 = 32 workgroups per
-        handle, and the launch places workgroup g on handle g % n, so with 8 handles every utterance runs on its own XCD
-        (32 CUs, one L2) and the eight pipelines are independent;
-      * otherwise handles of up to MAX_ROWS rows, as many per launch as fit.
-    VQW_AR_ROWS / VQW_AR_CPB override (measurements: tools/ar_layouts.py)."""
+    (generate.py:40,103-113), so how they are grouped into handles is free.  Measured at the reference widths
+    (tools/ar_layouts.py, us per step; profiles/round3_ar_layouts.txt):
+        rows   one handle   one-row handles, 8 channels per workgroup (R/8 = 32 workgroups each), ONE launch
+         1        65             --
+         2       103             66
+         4       127             94
+         8   129 (2 x 4 rows)   118 (8 x 32 workgroups = every CU of the chip)
+    One-row handles are independent pipelines: a handle's step time grows with its rows (every exchange carries B values per
+    channel and every dot product is formed B times), and side by side they only share the fabric the exchanges cross.
+      * up to MAX_GROUP rows that fit the chip as one-row handles: one row per handle, 8 channels per workgroup;
+      * otherwise handles of up to MAX_ROWS rows (more rows per weight byte streamed: the better AGGREGATE rate once the rows
+        no longer fit side by side), as many per launch as fit, the rest in further waves.
+    VQW_AR_ROWS / VQW_AR_CPB override."""
     import os
     rows = cpb = None
     if os.environ.get('VQW_AR_ROWS'):
         rows = max(1, min(MAX_ROWS, int(os.environ['VQW_AR_ROWS'])))
     if os.environ.get('VQW_AR_CPB') in ('4', '8'):
         cpb = int(os.environ['VQW_AR_CPB'])
-    if rows is None and cpb is None and MAX_ROWS < batch <= MAX_GROUP and R % 8 == 0 and (R // 8) * batch <= cus:
+    if rows is None and cpb is None and 1 < batch <= MAX_GROUP and R % 8 == 0 and (R // 8) * batch <= cus:
         return 1, 8
     if rows is None:
         n_parts = -(-batch // MAX_ROWS)
