@@ -763,17 +763,31 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
                         qf[j][e] = dg * sg[j][e] * (1.0f - th[j][e] * th[j][e]);
                         qg[j][e] = dg * th[j][e] * sg[j][e] * (1.0f - sg[j][e]);
                     }
-                    gmax = fmaxf(gmax, fmaxf(fabsf(qf[j][e]), fabsf(qg[j][e])));
-                    gbad |= !(fabsf(dg) <= 3.0e38f) || !(fabsf(qf[j][e]) <= 3.0e38f) || !(fabsf(qg[j][e]) <= 3.0e38f);
+                    // (a NaN / inf in dg or in the saved activations shows in qf / qg: the check below sees it)
                     pf[e * T + 32 * j] = qf[j][e];
                     pq[e * T + 32 * j] = qg[j][e];
                 }
             if (d.net_out_planes) {
+                // The max-abs / finiteness folds sit HERE, next to the plane stores and under the same condition, and are pinned by
+                // an empty asm: written in the arithmetic loop above, the optimiser sank them into the conditional guard_report at the
+                // end of the kernel and kept every qf / qg of the whole epilogue alive until then -- 150 (128-row blocks) to 290
+                // (256-row) spilled registers, 600-1200 bytes of scratch per lane (round 2's "spill-ridden epilogue").
+                float gm = 0.0f;
+                bool bad = false;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        gm = fmaxf(gm, fmaxf(fabsf(qf[j][e]), fabsf(qg[j][e])));
+                        bad |= !(fabsf(qf[j][e]) <= 3.0e38f) || !(fabsf(qg[j][e]) <= 3.0e38f);
+                    }
                     store_plane_quad<BF>(d.net_out_planes, PKC, a.NB, d.planes_kc0 + c0 / 8, n0 + 64 * wv + 32 * j + l31, lhi, qf[j], ps);
                     store_plane_quad<BF>(d.net_out_planes, PKC, a.NB, d.planes_kc0 + (R + c0) / 8, n0 + 64 * wv + 32 * j + l31, lhi, qg[j], ps);
                 }
+                gmax = fmaxf(gmax, gm);
+                int gb_i = (int)gbad | (int)bad;
+                asm volatile("" : "+v"(gmax), "+v"(gb_i));
+                gbad = gb_i != 0;
             }
         }
     if (d.net_out_planes) guard_report(gmax, gbad, ps, d.out_amax, d.flag);
@@ -1011,24 +1025,27 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         // a 16-byte window that straddles t = 0 (only with shifts that are not multiples of 4) is read from t = 0 and moved
         // up inside the register below; windows entirely before t = 0 read as zero through the buffer range check
         const int tl = tp >= 0 ? tp : (tp > -4 ? 0 : -1);
-        f32x4 w = vqw_buf_load4(rp, tl >= 0 ? (int)((prow + tl) * 4) : (int)0x80000000, 0);
-        if (ODD) {
-            const int k = (tp < 0 && tp > -4) ? -tp : 0;
-            f32x4 v;
-            v[0] = k == 0 ? w[0] : 0.0f;
-            v[1] = k == 0 ? w[1] : (k == 1 ? w[0] : 0.0f);
-            v[2] = k == 0 ? w[2] : (k == 1 ? w[1] : (k == 2 ? w[0] : 0.0f));
-            v[3] = k == 0 ? w[3] : (k == 1 ? w[2] : (k == 2 ? w[1] : w[0]));
-            w = v;
-        }
-        rgp[n] = w;
+        // (ODD: the straddling window is moved up when the registers are CONVERTED, commit_one -- doing it here, on the value just
+        // requested, made every request of the unaligned variant wait for its own data: 205 instead of 150 us per gate kernel)
+        rgp[n] = vqw_buf_load4(rp, tl >= 0 ? (int)((prow + tl) * 4) : (int)0x80000000, 0);
     };
     auto set_pair = [&](int s) { pb = s / a.pairs_row; pt0 = (s - pb * a.pairs_row) * 32; };
+    int pt0_c = 0;                                      // first time step of the pair being converted (ODD only)
+    auto set_commit_pair = [&](int s) { if (ODD) pt0_c = (s % a.pairs_row) * 32; };
     auto commit_one = [&](int n, int pair) {     // raw registers -> two fp16 planes -> LDS stage (2 pair + nn/2) % 4
         const int g = wv * 2 + (n >> 2), nn = n & 3;
         char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STG_BYTES + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
         uint2 lo;
         f32x4 pv = rgp[n];
+        if (ODD && !S2) {
+            const int tp = pt0_c + 8 * nn + 4 * hsel + shift;
+            const int k = (tp < 0 && tp > -4) ? -tp : 0;      // the window was read from t = 0: its first k elements lie before the row
+            const f32x4 w = pv;
+            pv[0] = k == 0 ? w[0] : 0.0f;
+            pv[1] = k == 0 ? w[1] : (k == 1 ? w[0] : 0.0f);
+            pv[2] = k == 0 ? w[2] : (k == 1 ? w[1] : (k == 2 ? w[0] : 0.0f));
+            pv[3] = k == 0 ? w[3] : (k == 1 ? w[2] : (k == 2 ? w[1] : w[0]));
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) pv[e] = fmaxf(pv[e], plo);
         uint2 hi = split4<BF>(pv, scp, lo);
@@ -1103,6 +1120,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const int npairs = s_end - s_begin;
     if (npairs > 0) {
         set_pair(s_begin);
+        set_commit_pair(s_begin);
 #pragma unroll
         for (int n = 0; n < 8; ++n) issue_one(n);
 #pragma unroll
@@ -1124,6 +1142,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             // (No conditionals inside: past the block's last pair the conversion rewrites stale registers into LDS stages
             // nobody reads again and the requests fall behind the end of the buffers, where raw buffer loads return zero --
             // branches would cut the body into scheduling regions and the MFMAs could no longer be interleaved.)
+            set_commit_pair(s_begin + it + 1);
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
                 mfma_rows(i, fb);
