@@ -496,6 +496,13 @@ typedef struct vqw_f16x3_wgrad_desc {
                              * T then only has to be a multiple of 4                                           */
     int32_t Tp;
     int32_t xcd_group;      /* ignored since round 3 (the block -> XCD placement is always K range, then tile, then tap) */
+    /* q as the operand planes its producer wrote anyway (vqw_f16x3_out_conv epi 1 writes dpre as planes for the input gradient and,
+     * with net_out = NULL, nothing else): [planes][q_planes_KC chunks][B*T rows][8] scaled by *q0_scale, this problem's Q0 rows from
+     * chunk q_planes_kc0.  q0 may then be NULL; Q1 = 0, p_stride 1.  q_total / q_seg are formed from the planes (2^-22 relative). */
+    const void* q_planes;
+    int32_t q_planes_KC;    /* 0 = Q0 / 8 */
+    int32_t q_planes_kc0;
+    float q_planes_scale;   /* host-side factor of the planes' scale (the producer's plane_scale), 0 = 1: planes = q * q_planes_scale * *q0_scale */
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
 /* `n` (<= 32) weight gradients of ONE shape in one launch -- the same kernels of several layers: d[i] may differ in p, q0, q1, dw,

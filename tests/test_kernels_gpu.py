@@ -794,6 +794,35 @@ def test_wgrad_f16x3_batch_of_layers_in_one_launch(K):
             sh = (2 - j) * d
             w64 = (nets[i][:, c, :T - sh].double() * dpres[i][:, o, sh:].double()).sum().item()
             assert abs(bat[i][j, c, o].item() - w64) <= 2e-6 * bat[i].abs().max().item(), (i, j, c, o)
+    # q as operand planes (what gate backward writes for the input gradient anyway) instead of fp32: the transposed LDS reads hand
+    # the MFMA the SAME fp16 pieces the in-register split makes -> dW bit-equal to the fp32-operand launch; the condition sums are
+    # formed from the planes (2^-22 relative)
+    for bf in (False, True):
+        md = K.X3_BF16 if bf else 0
+        planes = [torch.empty(2 * B * 2 * R * T, dtype=torch.float16, device=DEV) for _ in dils]
+        for i in range(len(dils)):
+            K.f16x3_split_activations(dpres[i], planes[i], B, 2 * R, T, scale_dev=scales[5 + i:6 + i], mode=md)
+        res = {}
+        for qp in (False, True):
+            dws = [torch.zeros(3, R, 2 * R, device=DEV) for _ in dils]
+            segs = [torch.zeros(B, 2 * R, Tz, device=DEV) for _ in dils]
+            probs = [dict(p=nets[i], dw=dws[i], taps=[-2 * d, -d, 0], p_scale=scales[i:i + 1], q0_scale=scales[5 + i:6 + i], q_seg=segs[i],
+                          **(dict(q_planes=planes[i]) if qp else dict(q0=dpres[i]))) for i, d in enumerate(dils)]
+            K.f16x3_wgrad_batch(probs, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, seg_T=Tz, mode=md)
+            res[qp] = (dws, segs)
+        for i in range(len(dils)):
+            assert torch.equal(res[True][0][i], res[False][0][i]), 'q from planes: dW of layer %d differs (bf16=%s)' % (i, bf)
+            close(res[True][1][i], dpres[i].view(B, 2 * R, Tz, T // Tz).sum(-1), rtol=3e-3 if bf else 1e-4, atol=3e-3 if bf else 1e-4,
+                  what='condition sums from planes, layer %d' % i)
+    # odd dilations (unaligned windows of p) with q from planes
+    dwa, dwb = torch.zeros(3, R, 2 * R, device=DEV), torch.zeros(3, R, 2 * R, device=DEV)
+    pl0 = torch.empty(2 * B * 2 * R * T, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(dpres[0], pl0, B, 2 * R, T, scale_dev=scales[5:6])
+    K.f16x3_wgrad(p=nets[0], q0=dpres[0], dw=dwa, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, taps=[-2, -1, 0], p_scale=scales[0:1], q0_scale=scales[5:6])
+    K.f16x3_wgrad(p=nets[0], q_planes=pl0, dw=dwb, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, taps=[-2, -1, 0], p_scale=scales[0:1], q0_scale=scales[5:6])
+    assert torch.equal(dwa, dwb)
+    w64 = (nets[0][:, 7, :T - 1].double() * dpres[0][:, 300, 1:].double()).sum().item()
+    assert abs(dwb[1, 7, 300].item() - w64) <= 2e-6 * dwb.abs().max().item()
     # residual halves: dW_r[l] = gated[l] (x) dnet[l+1] into columns S.. of [R][S+R], bias sums of dnet
     gated = [torch.randn(B, R, T, generator=gen).to(DEV) * 0.3 for _ in range(3)]
     dnets = [(torch.randn(B, R, T, generator=gen) * 3e-5).to(DEV) for _ in range(3)]

@@ -764,8 +764,10 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
                         qg[j][e] = dg * th[j][e] * sg[j][e] * (1.0f - sg[j][e]);
                     }
                     // (a NaN / inf in dg or in the saved activations shows in qf / qg: the check below sees it)
-                    pf[e * T + 32 * j] = qf[j][e];
-                    pq[e * T + 32 * j] = qg[j][e];
+                    if (d.net_out) {       // fp32 dpre only where somebody reads it (the batched weight gradients read the planes)
+                        pf[e * T + 32 * j] = qf[j][e];
+                        pq[e * T + 32 * j] = qg[j][e];
+                    }
                 }
             if (d.net_out_planes) {
                 // The max-abs / finiteness folds sit HERE, next to the plane stores and under the same condition, and are pinned by
@@ -923,6 +925,9 @@ struct WgProblem {
     float* q_total;       // [Q0 + Q1] += sum_{b,t} q[b][o][t]  (bias gradients) or NULL
     float* q_seg;         // [B][seg_bstride/..]: q_seg[b * seg_bstride + o * seg_T + t / seg_ratio] += q[b][o][t] (the transpose of
                           //   add_condition's upsampling, wavenet_ops.py:98-100) or NULL; seg_ratio % 32 == 0
+    const void* qp;       // QP kernels: q as operand planes [planes][q_KC chunks][B*T rows][8] (scaled by *sq0 * q_hscale), chunks from q_kc0
+    int q_KC, q_kc0;
+    float q_hscale;       // host-side part of the planes' scale (a power of two; 1 where the scale lives on the device)
     int shift[VQW_MAX_TAPS];
 };
 struct WgArgs {
@@ -976,9 +981,30 @@ __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
 // S2: p is the input of a stride-2 convolution (encoder.py:17-18): dW[j][c][o] += sum p[b][c][2 t + shift_j] q[b][o][t], shifts of
 // either sign, indices outside [0, Tp) are the conv's zero padding.  p is then fetched one float per request (stride 8 bytes
 // between the four of a chunk), each one range-checked on its own through the buffer descriptor.
-template <bool ODD, bool BF, bool S2 = false>
+// QP: q is not read as fp32 but as the OPERAND PLANES its producer wrote anyway (gate backward writes dpre as planes for the input
+// gradient; with this variant it no longer writes the 109 MB of fp32 dpre per layer at all).  Planes are channel-chunk-major --
+// 16 bytes = 8 channels of one time step -- while this contraction runs over TIME: the 16-byte entries go to LDS as they are, as a
+// [time step][channel] image per plane (rows of 512 + 64 bytes: the four rows of a transposed read fall into four different
+// 16-bank groups), and the B fragments are fetched with ds_read_b64_tr_b16, which hands lane (channel n, k half) its 4 + 4
+// consecutive time steps.  No conversion arithmetic for q (two thirds of the conversions of the gate kernels' gradient).
+constexpr int WG_QSTR = 576, WG_QPL = 16 * WG_QSTR;                       // bytes per time step / per plane of a stage's q image
+template <bool QP, bool BF> struct WgStage {
+    static constexpr int BYTES = QP ? 16 * 1024 + (BF ? 1 : 2) * WG_QPL : STG_BYTES;
+};
+__device__ __forceinline__ uint2 wg_tr_read(const char* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    const h4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(p));
+    return __builtin_bit_cast(uint2, v);
+#else
+    return make_uint2(0, 0);
+#endif
+}
+
+template <bool ODD, bool BF, bool S2 = false, bool QP = false>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int STGB = WgStage<QP, BF>::BYTES, NPL = BF ? 1 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const WgItem it = wg_decode(vqw_xcd_remap(blockIdx.x, gridDim.x), a);
     const WgProblem& pr = a.pr[it.prob];
@@ -988,12 +1014,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const bool from_q1 = o0 >= a.Q0;
     const float* qsrc = from_q1 ? pr.q1 : pr.q0;
     const int Qs = from_q1 ? a.Q1 : a.Q0, oq = from_q1 ? o0 - a.Q0 : o0;
-    const float scp = dev_scale(pr.sp), scq = dev_scale(from_q1 ? pr.sq1 : pr.sq0);
+    const float scp = dev_scale(pr.sp), scq = dev_scale(from_q1 ? pr.sq1 : pr.sq0) * (QP ? pr.q_hscale : 1.0f);
     const float plo = a.p_relu ? 0.0f : -INFINITY;
     const int T = a.T;
     const int s_begin = (int)((long)split * a.pairs_total / a.nsplit), s_end = (int)((long)(split + 1) * a.pairs_total / a.nsplit);
     const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(pr.p, (unsigned)((size_t)a.B * a.Cp * (S2 ? a.Tp : T) * 4));
-    const __amdgpu_buffer_rsrc_t rq = vqw_make_rsrc(qsrc, (unsigned)((size_t)a.B * Qs * T * 4));
+    const __amdgpu_buffer_rsrc_t rq = vqw_make_rsrc(QP ? reinterpret_cast<const float*>(pr.qp) : qsrc, (unsigned)((size_t)a.B * Qs * T * 4));
+    // QP: one resource per plane, based at this block's first chunk (32 chunks = its 256 q rows)
+    const size_t NBq = (size_t)a.B * T;
+    const char* qpb = reinterpret_cast<const char*>(pr.qp) + (QP ? ((size_t)pr.q_kc0 + o0 / 8) * NBq * 16 : 0);
+    const unsigned qspan = (unsigned)(32 * NBq * 16 < 0x7fffffffull ? 32 * NBq * 16 : 0x7fffffffull);
+    const __amdgpu_buffer_rsrc_t rqp0 = vqw_make_rsrc(qpb, qspan);
+    const __amdgpu_buffer_rsrc_t rqp1 = vqw_make_rsrc(qpb + (QP && !BF ? (size_t)pr.q_KC * NBq * 16 : 0), qspan);
     float* const q_total = pr.q_total;
     float* const q_seg = pr.q_seg;
 
@@ -1008,7 +1040,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         const int row = g * 32 + rsub;
         const int tq = pt0 + 8 * nn + 4 * hsel;
         // (S2: T need not be a multiple of the 32-step stage pairs -- steps behind the row's end read as zero)
-        rgq[n] = vqw_buf_load4(rq, (!S2 || tq < T) ? (int)((((size_t)pb * Qs + oq + row) * T + tq) * 4) : (int)0x80000000, 0);
+        if constexpr (QP) {
+            // item n of this thread: plane n / 4, chunks (n % 4) * 8 + lane % 8, time step 8 wv + lane / 8 of the pair's 32 --
+            // eight lanes = eight chunks of one step (128 contiguous bytes of LDS), eight lane groups = the eight steps of one
+            // 128-byte line per chunk
+            if (n < 4 * NPL) {
+                const int chunk = (n & 3) * 8 + (lane & 7), t = 8 * wv + (lane >> 3);
+                const int off = (int)(((size_t)chunk * NBq + (size_t)pb * T + pt0 + t) * 16);
+                rgq[n] = vqw_buf_load4((n >> 2) ? rqp1 : rqp0, off, 0);
+            }
+        } else {
+            rgq[n] = vqw_buf_load4(rq, (!S2 || tq < T) ? (int)((((size_t)pb * Qs + oq + row) * T + tq) * 4) : (int)0x80000000, 0);
+        }
         if (S2) {
             const size_t prow = ((size_t)pb * a.Cp + c0 + row) * a.Tp;
             f32x4 w;
@@ -1034,7 +1077,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     auto set_commit_pair = [&](int s) { if (ODD) pt0_c = (s % a.pairs_row) * 32; };
     auto commit_one = [&](int n, int pair) {     // raw registers -> two fp16 planes -> LDS stage (2 pair + nn/2) % 4
         const int g = wv * 2 + (n >> 2), nn = n & 3;
-        char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STG_BYTES + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
+        char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STGB + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
         uint2 lo;
         f32x4 pv = rgp[n];
         if (ODD && !S2) {
@@ -1051,9 +1094,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         uint2 hi = split4<BF>(pv, scp, lo);
         *reinterpret_cast<uint2*>(st + (g * 2 + 0) * 1024) = hi;
         if (!BF) *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
-        hi = split4<BF>(rgq[n], scq, lo);
-        *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 0) * 1024) = hi;
-        if (!BF) *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
+        if constexpr (QP) {
+            if (n < 4 * NPL) {     // the plane entry as it is: [time step][channel] image of its plane and stage
+                const int chunk = (n & 3) * 8 + (lane & 7), t = 8 * wv + (lane >> 3);
+                char* dq = smem + ((2 * pair + (t >> 4)) % NSTG) * STGB + 16 * 1024 + (n >> 2) * WG_QPL + (t & 15) * WG_QSTR + chunk * 16;
+                *reinterpret_cast<f32x4*>(dq) = rgq[n];
+            }
+        } else {
+            hi = split4<BF>(rgq[n], scq, lo);
+            *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 0) * 1024) = hi;
+            if (!BF) *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
+        }
     };
     // q sums (bias / condition gradients): the thread's two q rows (groups wv*2 and wv*2+1), its half of the 32 steps
     const bool do_sum = it.rtl == 0 && tap == 0 && (q_seg != nullptr || (q_total != nullptr && o0 < a.total_o1 && o0 + 256 > a.total_o0));
@@ -1062,34 +1113,77 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
 #ifdef VQW_ABL_WG_NOSUM
         return;
 #endif
+        if constexpr (QP) return;          // (QP: the sums are formed from the B fragments, sum_frag)
         const f32x4 v = rgq[n];
         qs_pair[n >> 2] += (v[0] + v[1]) + (v[2] + v[3]);
+    };
+    // QP: lane (channel n of column tile j, k half) holds 8 consecutive time steps of its channel per plane: their sum, over both
+    // planes, descaled -- the fp32 value to 2^-22 (the planes carry 22-23 significand bits)
+    const float inv_scq = __builtin_amdgcn_rcpf(scq);
+    auto sum_frag = [&](const uint4 (&b)[2][2]) {
+#ifdef VQW_ABL_WG_NOSUM
+        return;
+#endif
+        if constexpr (QP) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float acc_ = 0.0f;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const unsigned wds[4] = {b[j][pl].x, b[j][pl].y, b[j][pl].z, b[j][pl].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (BF) {
+                            acc_ += __uint_as_float(wds[e] << 16) + __uint_as_float(wds[e] & 0xffff0000u);
+                        } else {
+                            acc_ += (float)__builtin_bit_cast(_Float16, (u16)(wds[e] & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (u16)(wds[e] >> 16));
+                        }
+                    }
+                }
+                qs_pair[j] += acc_ * inv_scq;
+            }
+        }
     };
     auto flush_pair = [&](int s) {         // pair s is complete in qs_pair: add it to its condition frame, fold it into the totals
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float both = qs_pair[h] + __shfl_xor(qs_pair[h], 1, 64);      // the partner lane holds the other 16 steps
+            // the partner lane holds the other 16 steps (QP: the other k half of the fragment)
+            const float both = qs_pair[h] + __shfl_xor(qs_pair[h], QP ? 32 : 1, 64);
             qs_tot[h] += qs_pair[h];
             qs_pair[h] = 0.f;
-            if (q_seg && hsel == 0) {
+            if (q_seg && (QP ? lhi == 0 : hsel == 0)) {
                 const int b = s / a.pairs_row, t0 = (s - b * a.pairs_row) * 32;
-                const int row = o0 + (wv * 2 + h) * 32 + rsub;
+                const int row = o0 + (wv * 2 + h) * 32 + (QP ? l31 : rsub);
                 unsafeAtomicAdd(q_seg + (size_t)b * a.seg_bstride + (size_t)row * a.seg_T + t0 / a.seg_ratio, both);
             }
         }
     };
     uint4 fa[8][2], fb[2][2];                        // A fragments (both planes) of 8 row tiles, B fragments of this wave's 2 column tiles
     auto read_a = [&](int i, int stage) {
-        const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16;
+        const char* st = smem + (stage % NSTG) * STGB + lane * 16;
         fa[i][0] = *reinterpret_cast<const uint4*>(st + (i * 2 + 0) * 1024);
         if (!BF) fa[i][1] = *reinterpret_cast<const uint4*>(st + (i * 2 + 1) * 1024);
     };
+    // QP: 16-lane group G = lane / 16 reads rows (time steps) 8 (G / 2) + 4 r + 0..3, columns (channels) 64 wv + 32 j + 16 (G % 2) +
+    // 0..15 of the image; its lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3 and receives column lane % 16
+    const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * WG_QSTR + (64 * wv + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     auto read_b = [&](uint4 (&b)[2][2], int stage) {
-        const char* st = smem + (stage % NSTG) * STG_BYTES + lane * 16 + 16 * 1024;
+        if constexpr (QP) {
+            const char* st = smem + (stage % NSTG) * STGB + 16 * 1024 + tr_off;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pl = 0; pl < (BF ? 1 : 2); ++pl) b[j][pl] = *reinterpret_cast<const uint4*>(st + ((wv * 2 + j) * 2 + pl) * 1024);
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const uint2 k0 = wg_tr_read(st + j * 64 + pl * WG_QPL), k1 = wg_tr_read(st + j * 64 + pl * WG_QPL + 4 * WG_QSTR);
+                    b[j][pl] = make_uint4(k0.x, k0.y, k1.x, k1.y);
+                }
+        } else {
+            const char* st = smem + (stage % NSTG) * STGB + lane * 16 + 16 * 1024;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) b[j][pl] = *reinterpret_cast<const uint4*>(st + ((wv * 2 + j) * 2 + pl) * 1024);
+        }
     };
     f32x16 acc[8][2];
 #pragma unroll
@@ -1125,7 +1219,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         for (int n = 0; n < 8; ++n) issue_one(n);
 #pragma unroll
         for (int n = 0; n < 8; ++n) { commit_one(n, 0); sum_one(n); }
-        if (do_sum) flush_pair(s_begin);
+        if (!QP && do_sum) flush_pair(s_begin);
         set_pair(s_begin + 1);
 #pragma unroll
         for (int n = 0; n < 8; ++n) issue_one(n);
@@ -1133,6 +1227,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) read_a(i, 0);
         read_b(fb, 0);
+        sum_frag(fb);
         for (int it = 0; it < npairs; ++it) {
             // Stages 2it, 2it+1 (pair `it`) are in LDS, the fragments of stage 2it in registers; the raw operands of pair
             // it+1 are in rgp / rgq (requested one iteration ago).  Row tile by row tile: 6 MFMAs of the first stage, behind
@@ -1158,9 +1253,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
                     __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200, VQW_WG_PAT_A, 0);
                 }
             }
-            if (do_sum && it + 1 < npairs) flush_pair(s_begin + it + 1);
+            if (!QP && do_sum && it + 1 < npairs) flush_pair(s_begin + it + 1);
             set_pair(s_begin + it + 2);
             read_b(fb, 2 * it + 1);        // (after the first stage's last use of fb: 16 registers instead of 32)
+            sum_frag(fb);
+            if (QP && do_sum) flush_pair(s_begin + it);     // both stages of pair `it` have been read
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
                 mfma_rows(i, fb);
@@ -1176,6 +1273,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) read_a(i, 2 * it + 2);
             read_b(fb, 2 * it + 2);
+            sum_frag(fb);                  // (behind the last pair: a stale stage, never flushed)
         }
     }
     if (do_sum && q_total) {
@@ -1301,7 +1399,7 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(dp, "vqw_f16x3_out_conv: null descriptor");
     const vqw_f16x3_out_desc& d = *dp;
     VQW_CHECK(d.xp && d.wp, "vqw_f16x3_out_conv: null operand");
-    VQW_CHECK((d.S == 0 || d.skip) && (d.R == 0 || d.net_out), "vqw_f16x3_out_conv: null output");
+    VQW_CHECK((d.S == 0 || d.skip) && (d.R == 0 || d.net_out || (d.epi == 1 && d.net_out_planes)), "vqw_f16x3_out_conv: null output");
     VQW_CHECK(d.ks >= 0 && d.ks <= 8 && d.dilation >= 0, "vqw_f16x3_out_conv: bad kernel size %d / dilation %d", d.ks, d.dilation);
     VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_out_conv: T must be a positive multiple of 256 (got %d)", d.T);
     VQW_CHECK(d.R >= 0 && d.R % 256 == 0 && d.S >= 0 && d.S % 256 == 0 && d.S + d.R > 0, "vqw_f16x3_out_conv: R and S must be multiples of 256 (R=%d S=%d)", d.R, d.S);
@@ -1449,11 +1547,18 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
                   e.total_o1 == d.total_o1 && e.mode == d.mode && e.p_relu == d.p_relu && e.p_stride == d.p_stride && e.Tp == d.Tp &&
                   e.slab == d.slab && (e.q_seg != nullptr) == (d.q_seg != nullptr),
                   "vqw_f16x3_wgrad_batch: problem %d differs from problem 0 in shape or layout", i);
-        VQW_CHECK(e.p && e.q0 && e.dw && (e.Q1 == 0 || e.q1), "vqw_f16x3_wgrad: null operand (problem %d)", i);
+        VQW_CHECK(e.p && (e.q0 || e.q_planes) && e.dw && (e.Q1 == 0 || e.q1), "vqw_f16x3_wgrad: null operand (problem %d)", i);
+        VQW_CHECK((e.q_planes != nullptr) == (d.q_planes != nullptr), "vqw_f16x3_wgrad_batch: q as planes in every problem or in none");
+        if (e.q_planes) {
+            const int kc = e.q_planes_KC > 0 ? e.q_planes_KC : d.Q0 / 8;
+            VQW_CHECK(e.q_planes_kc0 >= 0 && e.q_planes_kc0 + d.Q0 / 8 <= kc, "vqw_f16x3_wgrad: bad chunk range of the q planes (kc0=%d KC=%d)", e.q_planes_kc0, kc);
+        }
         VQW_CHECK((reinterpret_cast<uintptr_t>(e.dw) & 15u) == 0, "vqw_f16x3_wgrad: dw must be 16-byte aligned (problem %d)", i);
         WgProblem& q = a.pr[i];
         q.p = e.p; q.q0 = e.q0; q.q1 = e.q1; q.dw = e.dw; q.sp = e.p_scale; q.sq0 = e.q0_scale; q.sq1 = e.q1_scale;
         q.q_total = e.q_total; q.q_seg = e.q_seg;
+        q.qp = e.q_planes; q.q_KC = e.q_planes_KC > 0 ? e.q_planes_KC : d.Q0 / 8; q.q_kc0 = e.q_planes_kc0;
+        q.q_hscale = e.q_planes_scale > 0.0f ? e.q_planes_scale : 1.0f;
         for (int j = 0; j < d.ntaps; ++j) {
             VQW_CHECK((s2 ? e.tap_shift[j] < (1 << 24) : e.tap_shift[j] <= 0) && e.tap_shift[j] > -(1 << 24),
                       "vqw_f16x3_wgrad: tap shifts must be <= 0 unless p_stride is 2 (problem %d, tap %d: %d)", i, j, e.tap_shift[j]);
@@ -1484,10 +1589,16 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
     typedef void (*kfn_t)(WgArgs);
     const kfn_t ktab[4] = {wgrad_f16x3_kernel<false, false>, wgrad_f16x3_kernel<true, false>, wgrad_f16x3_kernel<false, true>,
                            wgrad_f16x3_kernel<true, true>};
-    const kfn_t kfn = s2 ? wgrad_f16x3_kernel<false, false, true> : ktab[(odd ? 1 : 0) + 2 * (d.mode & 1)];
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STG_BYTES) != hipSuccess)
-        return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", NSTG * STG_BYTES);
-    hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), NSTG * STG_BYTES, st, a);
+    const kfn_t kqp[4] = {wgrad_f16x3_kernel<false, false, false, true>, wgrad_f16x3_kernel<true, false, false, true>,
+                          wgrad_f16x3_kernel<false, true, false, true>, wgrad_f16x3_kernel<true, true, false, true>};
+    const bool qp = d.q_planes != nullptr;
+    VQW_CHECK(!qp || (!s2 && d.Q1 == 0 && (size_t)32 * d.B * d.T * 16 < ((size_t)1 << 31)),
+              "vqw_f16x3_wgrad: q as planes needs p_stride 1, Q1 = 0 and B * T < 4 M");
+    const kfn_t kfn = s2 ? wgrad_f16x3_kernel<false, false, true> : (qp ? kqp : ktab)[(odd ? 1 : 0) + 2 * (d.mode & 1)];
+    const int lds = NSTG * (qp ? ((d.mode & 1) ? WgStage<true, true>::BYTES : WgStage<true, false>::BYTES) : STG_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), lds, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(65536 / 4 / 256, tiles), dim3(256), 0, st, a);
     VQW_LAUNCH_CHECK("vqw_f16x3_wgrad");
     return 0;

@@ -858,10 +858,19 @@ class VQVAE:
         # traffic (2 x 61 MB per single launch, 7.3 GB per step) falls with the batch size, dskip is read once per XCD instead
         # of once per layer, and 68 reductions become ~10.
         batched = bool(wg_x3) and os.environ.get('VQW_WGRAD_BATCH', '1') != '0'
-        if batched and 'dpre_all' not in ws:
-            ws['dpre_all'] = [A.empty(B, 2 * R, T, device=self.dev) for _ in range(L)]
+        # ... and dpre is kept as the operand PLANES gate backward writes for the input gradient anyway: the gate kernels' weight
+        # gradient reads its q operand from them (transposed LDS reads, vqw_f16x3_wgrad q_planes) and gate backward no longer
+        # writes fp32 dpre at all (109 of its 312 MB per layer)
+        qp = batched and os.environ.get('VQW_WGRAD_QP', '1') != '0'
+        if batched and 'dnet_all' not in ws:
             ws['dnet_all'] = [A.empty(B, R, T, device=self.dev) for _ in range(L)]       # dnet_all[l] = d loss / d net[l]
-            ws['_poison'] += ws['dpre_all'] + ws['dnet_all']
+            ws['_poison'] += ws['dnet_all']
+        if batched and ('dp_all' if qp else 'dpre_all') not in ws:
+            if qp:
+                ws['dp_all'] = [A.empty(2 * B * 2 * R * T, dtype=torch.float16, device=self.dev) for _ in range(L)]
+            else:
+                ws['dpre_all'] = [A.empty(B, 2 * R, T, device=self.dev) for _ in range(L)]
+            ws['_poison'] += ws['dp_all' if qp else 'dpre_all']
         gate_batch = int(os.environ.get('VQW_WG_GATE_BATCH', '6'))      # 36 tiles x 7 K splits = 252 blocks (tools/wg_batch_sweep.sh)
         res_batch = int(os.environ.get('VQW_WG_RES_BATCH', '29'))
         pend_gate, pend_res = {False: [], True: []}, []
@@ -878,8 +887,9 @@ class VQVAE:
         def flush_gate(odd):
             layers, pend_gate[odd] = pend_gate[odd], []
             if layers:
-                probs = [dict(p=net[i], q0=ws['dpre_all'][i], dw=G['gated_w'][i], taps=[-(ks - 1 - j) * self.dil[i] for j in range(ks)],
-                              p_scale=sc('X', i), q0_scale=sc('DP', i), q_seg=dce.view(-1)[i * 2 * R * Tz:]) for i in layers]
+                probs = [dict(p=net[i], dw=G['gated_w'][i], taps=[-(ks - 1 - j) * self.dil[i] for j in range(ks)],
+                              p_scale=sc('X', i), q0_scale=sc('DP', i), q_seg=dce.view(-1)[i * 2 * R * Tz:],
+                              **(dict(q_planes=ws['dp_all'][i], q_planes_scale=GS) if qp else dict(q0=ws['dpre_all'][i]))) for i in layers]
                 on_side(lambda: K.f16x3_wgrad_batch(probs, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=2 * R, seg_T=Tz, seg_bstride=cbs, mode=md))
 
         def flush_res():
@@ -901,7 +911,8 @@ class VQVAE:
         for l in range(L - 1, -1, -1):
             d = self.dil[l]
             top = (l == L - 1)       # net[L] is unused by the graph: its gradient is zero
-            dpre = ws['dpre_all'][l] if batched else dpre_ring[l % 2]
+            dpre = (None if qp else ws['dpre_all'][l]) if batched else dpre_ring[l % 2]
+            dplanes = ws['dp_all'][l] if qp else ws.get('dp')
             dnet_next = ws['dnet_all'][l] if batched else dnet_ring[(l - 1) % 3]
             if not batched and side is not main and (l + 2) in side_done:
                 main.wait_event(side_done[l + 2])            # dpre[l % 2] and dnet[(l - 1) % 3] are free again
@@ -909,7 +920,7 @@ class VQVAE:
                 K.f16x3_out_conv(epi=1, xp=ws['gr'], Cin=S if top else S + R, xp_KC=(S + R) // 8,
                                  wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=ws['gated'][l] if th_dropped else ws['th'][l],
                                  aux0_is_gated=th_dropped, aux1=ws['sg'][l], net_out=dpre,
-                                 net_out_planes=ws['dp'], plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (WS * GS),
+                                 net_out_planes=dplanes, plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (WS * GS),
                                  x_scale=sc('G'), w_scale=sc('WO'), out_scale=sc('DP', l), out_amax=am('DP', l), flag=flag, mode=md)
             else:
                 K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
@@ -924,7 +935,7 @@ class VQVAE:
             if dgrad_x3:
                 if not gbwd_x3:      # (gate backward hands dpre over as planes)
                     K.f16x3_split_activations(dpre, ws['dp'], B, 2 * R, T, scale=GS, mode=md)
-                K.f16x3_out_conv(xp=ws['dp'], Cin=2 * R, ks=ks, dilation=d, direction=-1, wp=ws['wdg'][l],
+                K.f16x3_out_conv(xp=dplanes, Cin=2 * R, ks=ks, dilation=d, direction=-1, wp=ws['wdg'][l],
                                  net_in=None if top else dnet, net_out=dnet_next, B=B, T=T, R=R, S=0,
                                  w_scale_inv=1.0 / (WS * GS),
                                  net_out_planes=ws['gr'] if gbwd_x3 else None, planes_kc0=S // 8 if gbwd_x3 else 0,
