@@ -503,6 +503,12 @@ typedef struct vqw_f16x3_wgrad_desc {
     int32_t q_planes_KC;    /* 0 = Q0 / 8 */
     int32_t q_planes_kc0;
     float q_planes_scale;   /* host-side factor of the planes' scale (the producer's plane_scale), 0 = 1: planes = q * q_planes_scale * *q0_scale */
+    /* p likewise (the layer-input planes of vqw_f16x3_out_conv / the gated planes of vqw_f16x3_gate_conv): a tap's shift is then a row
+     * offset of the planes, so shifts that are not multiples of 4 cost nothing extra.  p may be NULL; p_stride 1, no p_relu.        */
+    const void* p_planes;
+    int32_t p_planes_KC;    /* 0 = Cp / 8 */
+    int32_t p_planes_kc0;
+    float p_planes_scale;
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
 /* `n` (<= 32) weight gradients of ONE shape in one launch -- the same kernels of several layers: d[i] may differ in p, q0, q1, dw,

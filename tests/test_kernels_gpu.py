@@ -823,6 +823,34 @@ def test_wgrad_f16x3_batch_of_layers_in_one_launch(K):
     assert torch.equal(dwa, dwb)
     w64 = (nets[0][:, 7, :T - 1].double() * dpres[0][:, 300, 1:].double()).sum().item()
     assert abs(dwb[1, 7, 300].item() - w64) <= 2e-6 * dwb.abs().max().item()
+    # p as planes too (the layer-input planes of the forward pass): a shift is a row offset, also where it is not a multiple of 4;
+    # all four operand combinations give the same bits
+    npl = torch.empty(2 * B * R * T, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(nets[0], npl, B, R, T, scale_dev=scales[0:1])
+    for taps in ([-2, -1, 0], [-16, -8, 0], [-1024, -512, 0]):
+        ref = torch.zeros(3, R, 2 * R, device=DEV)
+        K.f16x3_wgrad(p=nets[0], q0=dpres[0], dw=ref, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, taps=taps, p_scale=scales[0:1], q0_scale=scales[5:6])
+        for qp in (False, True):
+            got = torch.zeros(3, R, 2 * R, device=DEV)
+            seg = torch.zeros(B, 2 * R, Tz, device=DEV)
+            K.f16x3_wgrad(p_planes=npl, dw=got, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, taps=taps, p_scale=scales[0:1], q0_scale=scales[5:6],
+                          q_seg=seg, seg_T=Tz, **(dict(q_planes=pl0) if qp else dict(q0=dpres[0])))
+            assert torch.equal(got, ref), 'p from planes (q from planes: %s), taps %s' % (qp, taps)
+            close(seg, dpres[0].view(B, 2 * R, Tz, T // Tz).sum(-1), rtol=1e-4, atol=1e-4, what='condition sums')
+    # p planes inside a wider planes tensor (the gated planes of all layers side by side), batched
+    gall = torch.empty(2 * B * 3 * R * T, dtype=torch.float16, device=DEV)
+    gs = [torch.randn(B, R, T, generator=gen).to(DEV) * 0.3 for _ in range(3)]
+    for i in range(3):
+        K.f16x3_split_activations(gs[i], gall, B, R, T, kc0=i * (R // 8), KC=3 * (R // 8))
+    dsk = (torch.randn(B, S, T, generator=gen) * 1e-5).to(DEV)
+    a_ = [torch.zeros(R, S + R, device=DEV) for _ in range(3)]
+    b_ = [torch.zeros(R, S + R, device=DEV) for _ in range(3)]
+    K.f16x3_wgrad_batch([dict(p=gs[i], dw=a_[i].view(-1)) for i in range(3)], q0=dsk, slab=slab, B=B, T=T, Cp=R, Q0=S, lddw=S + R,
+                        taps=[0], q0_scale=scales[6:7])
+    K.f16x3_wgrad_batch([dict(p_planes=gall, p_planes_kc0=i * (R // 8), dw=b_[i].view(-1)) for i in range(3)], p_planes_KC=3 * (R // 8),
+                        q0=dsk, slab=slab, B=B, T=T, Cp=R, Q0=S, lddw=S + R, taps=[0], q0_scale=scales[6:7])
+    for i in range(3):
+        assert torch.equal(a_[i], b_[i])
     # residual halves: dW_r[l] = gated[l] (x) dnet[l+1] into columns S.. of [R][S+R], bias sums of dnet
     gated = [torch.randn(B, R, T, generator=gen).to(DEV) * 0.3 for _ in range(3)]
     dnets = [(torch.randn(B, R, T, generator=gen) * 3e-5).to(DEV) for _ in range(3)]

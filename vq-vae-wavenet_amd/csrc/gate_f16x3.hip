@@ -928,6 +928,9 @@ struct WgProblem {
     const void* qp;       // QP kernels: q as operand planes [planes][q_KC chunks][B*T rows][8] (scaled by *sq0 * q_hscale), chunks from q_kc0
     int q_KC, q_kc0;
     float q_hscale;       // host-side part of the planes' scale (a power of two; 1 where the scale lives on the device)
+    const void* pp;       // PP kernels: p as operand planes, likewise
+    int p_KC, p_kc0;
+    float p_hscale;
     int shift[VQW_MAX_TAPS];
 };
 struct WgArgs {
@@ -988,8 +991,11 @@ __device__ __forceinline__ uint2 split4(const f32x4 v, float sc, uint2& lo) {
 // 16-bank groups), and the B fragments are fetched with ds_read_b64_tr_b16, which hands lane (channel n, k half) its 4 + 4
 // consecutive time steps.  No conversion arithmetic for q (two thirds of the conversions of the gate kernels' gradient).
 constexpr int WG_QSTR = 576, WG_QPL = 16 * WG_QSTR;                       // bytes per time step / per plane of a stage's q image
-template <bool QP, bool BF> struct WgStage {
-    static constexpr int BYTES = QP ? 16 * 1024 + (BF ? 1 : 2) * WG_QPL : STG_BYTES;
+// PP: the same for p (the layer input planes the forward pass wrote, the gated planes): a tap's shift is then a row offset of
+// the planes -- no unaligned 16-byte windows, no ODD variant -- and the loop converts nothing at all.
+template <bool QP, bool PP, bool BF> struct WgStage {
+    static constexpr int BOFF = PP ? (BF ? 1 : 2) * WG_QPL : 16 * 1024;            // q image behind the p image
+    static constexpr int BYTES = BOFF + (QP ? (BF ? 1 : 2) * WG_QPL : 16 * 1024);
 };
 __device__ __forceinline__ uint2 wg_tr_read(const char* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1001,10 +1007,10 @@ __device__ __forceinline__ uint2 wg_tr_read(const char* p) {
 #endif
 }
 
-template <bool ODD, bool BF, bool S2 = false, bool QP = false>
+template <bool ODD, bool BF, bool S2 = false, bool QP = false, bool PP = false>
 __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int STGB = WgStage<QP, BF>::BYTES, NPL = BF ? 1 : 2;
+    constexpr int STGB = WgStage<QP, PP, BF>::BYTES, BOFF = WgStage<QP, PP, BF>::BOFF, NPL = BF ? 1 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const WgItem it = wg_decode(vqw_xcd_remap(blockIdx.x, gridDim.x), a);
     const WgProblem& pr = a.pr[it.prob];
@@ -1014,11 +1020,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const bool from_q1 = o0 >= a.Q0;
     const float* qsrc = from_q1 ? pr.q1 : pr.q0;
     const int Qs = from_q1 ? a.Q1 : a.Q0, oq = from_q1 ? o0 - a.Q0 : o0;
-    const float scp = dev_scale(pr.sp), scq = dev_scale(from_q1 ? pr.sq1 : pr.sq0) * (QP ? pr.q_hscale : 1.0f);
+    const float scp = dev_scale(pr.sp) * (PP ? pr.p_hscale : 1.0f), scq = dev_scale(from_q1 ? pr.sq1 : pr.sq0) * (QP ? pr.q_hscale : 1.0f);
     const float plo = a.p_relu ? 0.0f : -INFINITY;
     const int T = a.T;
     const int s_begin = (int)((long)split * a.pairs_total / a.nsplit), s_end = (int)((long)(split + 1) * a.pairs_total / a.nsplit);
-    const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(pr.p, (unsigned)((size_t)a.B * a.Cp * (S2 ? a.Tp : T) * 4));
+    const __amdgpu_buffer_rsrc_t rp = vqw_make_rsrc(PP ? reinterpret_cast<const float*>(pr.pp) : pr.p, (unsigned)((size_t)a.B * a.Cp * (S2 ? a.Tp : T) * 4));
     const __amdgpu_buffer_rsrc_t rq = vqw_make_rsrc(QP ? reinterpret_cast<const float*>(pr.qp) : qsrc, (unsigned)((size_t)a.B * Qs * T * 4));
     // QP: one resource per plane, based at this block's first chunk (32 chunks = its 256 q rows)
     const size_t NBq = (size_t)a.B * T;
@@ -1026,6 +1032,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const unsigned qspan = (unsigned)(32 * NBq * 16 < 0x7fffffffull ? 32 * NBq * 16 : 0x7fffffffull);
     const __amdgpu_buffer_rsrc_t rqp0 = vqw_make_rsrc(qpb, qspan);
     const __amdgpu_buffer_rsrc_t rqp1 = vqw_make_rsrc(qpb + (QP && !BF ? (size_t)pr.q_KC * NBq * 16 : 0), qspan);
+    const char* ppb = reinterpret_cast<const char*>(pr.pp) + (PP ? ((size_t)pr.p_kc0 + c0 / 8) * NBq * 16 : 0);
+    const __amdgpu_buffer_rsrc_t rpp0 = vqw_make_rsrc(ppb, qspan);
+    const __amdgpu_buffer_rsrc_t rpp1 = vqw_make_rsrc(ppb + (PP && !BF ? (size_t)pr.p_KC * NBq * 16 : 0), qspan);
     float* const q_total = pr.q_total;
     float* const q_seg = pr.q_seg;
 
@@ -1051,6 +1060,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             }
         } else {
             rgq[n] = vqw_buf_load4(rq, (!S2 || tq < T) ? (int)((((size_t)pb * Qs + oq + row) * T + tq) * 4) : (int)0x80000000, 0);
+        }
+        if constexpr (PP) {      // the same item geometry as QP; the tap's shift is a row offset, rows before the batch row read as zero
+            if (n < 4 * NPL) {
+                const int chunk = (n & 3) * 8 + (lane & 7), tt = pt0 + 8 * wv + (lane >> 3) + shift;
+                const int off = tt >= 0 ? (int)(((size_t)chunk * NBq + (size_t)pb * T + tt) * 16) : (int)0x80000000;
+                rgp[n] = vqw_buf_load4((n >> 2) ? rpp1 : rpp0, off, 0);
+            }
+            return;
         }
         if (S2) {
             const size_t prow = ((size_t)pb * a.Cp + c0 + row) * a.Tp;
@@ -1079,7 +1096,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         const int g = wv * 2 + (n >> 2), nn = n & 3;
         char* st = smem + ((2 * pair + (nn >> 1)) % NSTG) * STGB + ((nn & 1) * 32 + rsub) * 16 + hsel * 8;
         uint2 lo;
+        uint2 hi;
         f32x4 pv = rgp[n];
+        if constexpr (PP) {
+            if (n < 4 * NPL) {
+                const int chunk = (n & 3) * 8 + (lane & 7), t = 8 * wv + (lane >> 3);
+                char* dp_ = smem + ((2 * pair + (t >> 4)) % NSTG) * STGB + (n >> 2) * WG_QPL + (t & 15) * WG_QSTR + chunk * 16;
+                *reinterpret_cast<f32x4*>(dp_) = pv;
+            }
+        } else {
         if (ODD && !S2) {
             const int tp = pt0_c + 8 * nn + 4 * hsel + shift;
             const int k = (tp < 0 && tp > -4) ? -tp : 0;      // the window was read from t = 0: its first k elements lie before the row
@@ -1091,19 +1116,20 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) pv[e] = fmaxf(pv[e], plo);
-        uint2 hi = split4<BF>(pv, scp, lo);
+        hi = split4<BF>(pv, scp, lo);
         *reinterpret_cast<uint2*>(st + (g * 2 + 0) * 1024) = hi;
         if (!BF) *reinterpret_cast<uint2*>(st + (g * 2 + 1) * 1024) = lo;
+        }
         if constexpr (QP) {
             if (n < 4 * NPL) {     // the plane entry as it is: [time step][channel] image of its plane and stage
                 const int chunk = (n & 3) * 8 + (lane & 7), t = 8 * wv + (lane >> 3);
-                char* dq = smem + ((2 * pair + (t >> 4)) % NSTG) * STGB + 16 * 1024 + (n >> 2) * WG_QPL + (t & 15) * WG_QSTR + chunk * 16;
+                char* dq = smem + ((2 * pair + (t >> 4)) % NSTG) * STGB + BOFF + (n >> 2) * WG_QPL + (t & 15) * WG_QSTR + chunk * 16;
                 *reinterpret_cast<f32x4*>(dq) = rgq[n];
             }
         } else {
             hi = split4<BF>(rgq[n], scq, lo);
-            *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 0) * 1024) = hi;
-            if (!BF) *reinterpret_cast<uint2*>(st + 16 * 1024 + (g * 2 + 1) * 1024) = lo;
+            *reinterpret_cast<uint2*>(st + BOFF + (g * 2 + 0) * 1024) = hi;
+            if (!BF) *reinterpret_cast<uint2*>(st + BOFF + (g * 2 + 1) * 1024) = lo;
         }
     };
     // q sums (bias / condition gradients): the thread's two q rows (groups wv*2 and wv*2+1), its half of the 32 steps
@@ -1159,17 +1185,27 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         }
     };
     uint4 fa[8][2], fb[2][2];                        // A fragments (both planes) of 8 row tiles, B fragments of this wave's 2 column tiles
+    // transposed reads (QP / PP): 16-lane group G = lane / 16 reads rows (time steps) 8 (G / 2) + 4 r + 0..3, 16 columns (channels)
+    // from 16 (G % 2) of the 32-channel tile; its lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3 and receives
+    // column lane % 16
+    const int tr_lane = (8 * (lane >> 5) + ((lane & 15) >> 2)) * WG_QSTR + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     auto read_a = [&](int i, int stage) {
-        const char* st = smem + (stage % NSTG) * STGB + lane * 16;
-        fa[i][0] = *reinterpret_cast<const uint4*>(st + (i * 2 + 0) * 1024);
-        if (!BF) fa[i][1] = *reinterpret_cast<const uint4*>(st + (i * 2 + 1) * 1024);
+        if constexpr (PP) {
+            const char* st = smem + (stage % NSTG) * STGB + tr_lane + i * 64;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const uint2 k0 = wg_tr_read(st + pl * WG_QPL), k1 = wg_tr_read(st + pl * WG_QPL + 4 * WG_QSTR);
+                fa[i][pl] = make_uint4(k0.x, k0.y, k1.x, k1.y);
+            }
+        } else {
+            const char* st = smem + (stage % NSTG) * STGB + lane * 16;
+            fa[i][0] = *reinterpret_cast<const uint4*>(st + (i * 2 + 0) * 1024);
+            if (!BF) fa[i][1] = *reinterpret_cast<const uint4*>(st + (i * 2 + 1) * 1024);
+        }
     };
-    // QP: 16-lane group G = lane / 16 reads rows (time steps) 8 (G / 2) + 4 r + 0..3, columns (channels) 64 wv + 32 j + 16 (G % 2) +
-    // 0..15 of the image; its lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3 and receives column lane % 16
-    const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * WG_QSTR + (64 * wv + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     auto read_b = [&](uint4 (&b)[2][2], int stage) {
         if constexpr (QP) {
-            const char* st = smem + (stage % NSTG) * STGB + 16 * 1024 + tr_off;
+            const char* st = smem + (stage % NSTG) * STGB + BOFF + tr_lane + wv * 128;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1178,7 +1214,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
                     b[j][pl] = make_uint4(k0.x, k0.y, k1.x, k1.y);
                 }
         } else {
-            const char* st = smem + (stage % NSTG) * STGB + lane * 16 + 16 * 1024;
+            const char* st = smem + (stage % NSTG) * STGB + lane * 16 + BOFF;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1547,8 +1583,13 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
                   e.total_o1 == d.total_o1 && e.mode == d.mode && e.p_relu == d.p_relu && e.p_stride == d.p_stride && e.Tp == d.Tp &&
                   e.slab == d.slab && (e.q_seg != nullptr) == (d.q_seg != nullptr),
                   "vqw_f16x3_wgrad_batch: problem %d differs from problem 0 in shape or layout", i);
-        VQW_CHECK(e.p && (e.q0 || e.q_planes) && e.dw && (e.Q1 == 0 || e.q1), "vqw_f16x3_wgrad: null operand (problem %d)", i);
-        VQW_CHECK((e.q_planes != nullptr) == (d.q_planes != nullptr), "vqw_f16x3_wgrad_batch: q as planes in every problem or in none");
+        VQW_CHECK((e.p || e.p_planes) && (e.q0 || e.q_planes) && e.dw && (e.Q1 == 0 || e.q1), "vqw_f16x3_wgrad: null operand (problem %d)", i);
+        VQW_CHECK((e.q_planes != nullptr) == (d.q_planes != nullptr) && (e.p_planes != nullptr) == (d.p_planes != nullptr),
+                  "vqw_f16x3_wgrad_batch: an operand as planes in every problem or in none");
+        if (e.p_planes) {
+            const int kc = e.p_planes_KC > 0 ? e.p_planes_KC : d.Cp / 8;
+            VQW_CHECK(e.p_planes_kc0 >= 0 && e.p_planes_kc0 + d.Cp / 8 <= kc, "vqw_f16x3_wgrad: bad chunk range of the p planes (kc0=%d KC=%d)", e.p_planes_kc0, kc);
+        }
         if (e.q_planes) {
             const int kc = e.q_planes_KC > 0 ? e.q_planes_KC : d.Q0 / 8;
             VQW_CHECK(e.q_planes_kc0 >= 0 && e.q_planes_kc0 + d.Q0 / 8 <= kc, "vqw_f16x3_wgrad: bad chunk range of the q planes (kc0=%d KC=%d)", e.q_planes_kc0, kc);
@@ -1559,6 +1600,8 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
         q.q_total = e.q_total; q.q_seg = e.q_seg;
         q.qp = e.q_planes; q.q_KC = e.q_planes_KC > 0 ? e.q_planes_KC : d.Q0 / 8; q.q_kc0 = e.q_planes_kc0;
         q.q_hscale = e.q_planes_scale > 0.0f ? e.q_planes_scale : 1.0f;
+        q.pp = e.p_planes; q.p_KC = e.p_planes_KC > 0 ? e.p_planes_KC : d.Cp / 8; q.p_kc0 = e.p_planes_kc0;
+        q.p_hscale = e.p_planes_scale > 0.0f ? e.p_planes_scale : 1.0f;
         for (int j = 0; j < d.ntaps; ++j) {
             VQW_CHECK((s2 ? e.tap_shift[j] < (1 << 24) : e.tap_shift[j] <= 0) && e.tap_shift[j] > -(1 << 24),
                       "vqw_f16x3_wgrad: tap shifts must be <= 0 unless p_stride is 2 (problem %d, tap %d: %d)", i, j, e.tap_shift[j]);
@@ -1591,11 +1634,18 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
                            wgrad_f16x3_kernel<true, true>};
     const kfn_t kqp[4] = {wgrad_f16x3_kernel<false, false, false, true>, wgrad_f16x3_kernel<true, false, false, true>,
                           wgrad_f16x3_kernel<false, true, false, true>, wgrad_f16x3_kernel<true, true, false, true>};
-    const bool qp = d.q_planes != nullptr;
+    const bool qp = d.q_planes != nullptr, pp = d.p_planes != nullptr, bf = (d.mode & 1) != 0;
     VQW_CHECK(!qp || (!s2 && d.Q1 == 0 && (size_t)32 * d.B * d.T * 16 < ((size_t)1 << 31)),
               "vqw_f16x3_wgrad: q as planes needs p_stride 1, Q1 = 0 and B * T < 4 M");
-    const kfn_t kfn = s2 ? wgrad_f16x3_kernel<false, false, true> : (qp ? kqp : ktab)[(odd ? 1 : 0) + 2 * (d.mode & 1)];
-    const int lds = NSTG * (qp ? ((d.mode & 1) ? WgStage<true, true>::BYTES : WgStage<true, false>::BYTES) : STG_BYTES);
+    VQW_CHECK(!pp || (!s2 && !d.p_relu && (size_t)32 * d.B * d.T * 16 < ((size_t)1 << 31)),
+              "vqw_f16x3_wgrad: p as planes needs p_stride 1, no p_relu and B * T < 4 M");
+    // (p as planes: a tap's shift is a row offset -- the unaligned-window variant is not needed)
+    const kfn_t kpp[4] = {wgrad_f16x3_kernel<false, false, false, false, true>, wgrad_f16x3_kernel<false, true, false, false, true>,
+                          wgrad_f16x3_kernel<false, false, false, true, true>, wgrad_f16x3_kernel<false, true, false, true, true>};
+    const kfn_t kfn = s2 ? wgrad_f16x3_kernel<false, false, true>
+                         : (pp ? kpp[(bf ? 1 : 0) + (qp ? 2 : 0)] : (qp ? kqp : ktab)[(odd ? 1 : 0) + 2 * (bf ? 1 : 0)]);
+    const int npl = bf ? 1 : 2;
+    const int lds = NSTG * ((pp ? npl * WG_QPL : 16 * 1024) + (qp ? npl * WG_QPL : 16 * 1024));
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_wgrad: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL(kfn, dim3(tiles * nsplit), dim3(256), lds, st, a);

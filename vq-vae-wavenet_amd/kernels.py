@@ -402,15 +402,20 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     L.check(L.lib().vqw_f16x3_gate_conv(C.byref(d), L.stream()))
 
 
-def _wgrad_desc(d, *, p, dw, slab, B, T, Cp, Q0, taps, q0=None, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
+def _wgrad_desc(d, *, dw, slab, B, T, Cp, Q0, taps, p=None, q0=None, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
                 q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=None,
-                p_stride=1, T_p=None, p_relu=False, q_planes=None, q_planes_KC=0, q_planes_kc0=0, q_planes_scale=0.0):
+                p_stride=1, T_p=None, p_relu=False, q_planes=None, q_planes_KC=0, q_planes_kc0=0, q_planes_scale=0.0,
+                p_planes=None, p_planes_KC=0, p_planes_kc0=0, p_planes_scale=0.0):
     """q_planes: q0 as operand planes [planes][q_planes_KC or Q0/8 chunks][B*T][8] (scaled by q0_scale) instead of fp32."""
     mode = x3_mode(mode)
     T_p = T if T_p is None else T_p
     lddw = (Q0 + Q1) if lddw is None else lddw
     dw_tap_stride = Cp * lddw if dw_tap_stride is None else dw_tap_stride
-    _need(p, B * Cp * T_p, 'p')
+    if p_planes is not None:
+        _need_planes(p_planes, (1 if mode & X3_BF16 else 2) * (p_planes_KC or Cp // 8) * 8 * B * T, 'p_planes')
+        d.p_planes, d.p_planes_KC, d.p_planes_kc0, d.p_planes_scale = p_planes.data_ptr(), p_planes_KC, p_planes_kc0, float(p_planes_scale)
+    else:
+        _need(p, B * Cp * T_p, 'p')
     if q_planes is not None:
         _need_planes(q_planes, (1 if mode & X3_BF16 else 2) * (q_planes_KC or Q0 // 8) * 8 * B * T, 'q_planes')
         d.q_planes, d.q_planes_KC, d.q_planes_kc0, d.q_planes_scale = q_planes.data_ptr(), q_planes_KC, q_planes_kc0, float(q_planes_scale)
@@ -421,7 +426,7 @@ def _wgrad_desc(d, *, p, dw, slab, B, T, Cp, Q0, taps, q0=None, q1=None, Q1=0, l
     _need(dw, (len(taps) - 1) * dw_tap_stride + (Cp - 1) * lddw + Q0 + Q1, 'dw')
     _need(slab, 65536, 'slab')
     d.p_stride, d.Tp, d.p_relu = p_stride, T_p, int(bool(p_relu))
-    d.p, d.q0, d.q1, d.dw, d.slab = p.data_ptr(), (None if q0 is None else q0.data_ptr()), (None if q1 is None else q1.data_ptr()), dw.data_ptr(), slab.data_ptr()
+    d.p, d.q0, d.q1, d.dw, d.slab = (None if p is None else p.data_ptr()), (None if q0 is None else q0.data_ptr()), (None if q1 is None else q1.data_ptr()), dw.data_ptr(), slab.data_ptr()
     d.slab_floats = slab.numel()
     d.p_scale, d.q0_scale, d.q1_scale = _slot(p_scale, 'p_scale'), _slot(q0_scale, 'q0_scale'), _slot(q1_scale, 'q1_scale')
     d.B, d.T, d.Cp, d.Q0, d.Q1, d.ntaps = B, T, Cp, Q0, Q1, len(taps)

@@ -122,6 +122,7 @@ class VQVAE:
         self.skip_f16x3 = ladder in ('3', '4', '5')
         self.dgrad_f16x3 = ladder in ('4', '5')
         self.gbwd_f16x3 = ladder == '5'
+        self.wg_planes = os.environ.get('VQW_WGRAD_PP', '1') != '0'      # weight gradients read p from operand planes too
         self._x3_active = True         # False while a step is being repeated on the fp32 engine
         self._x3_warned = set()        # (B, T) shapes already reported as running on the fp32 engine
         self.x3_fallbacks = 0          # steps repeated on the fp32 engine because a plane left fp16's range
@@ -388,6 +389,9 @@ class VQVAE:
         ws['sg'] = [e(B, R, T) for _ in range(L)]
         if self.gate_f16x3:
             ws['xp'] = A.empty(2 * B * R * T, dtype=torch.float16, device=dev)
+            # the input planes of EVERY layer are kept (1.6 GB at B = 8) where the weight gradients read them (backward: p_planes)
+            if self.x3_all and self.wg_planes:
+                ws['xp_all'] = [ws['xp']] + [A.empty(2 * B * R * T, dtype=torch.float16, device=dev) for _ in range(L)]
             ws['wp_all'] = A.empty(L, 2 * self.ks * R * 2 * R, dtype=torch.float16, device=dev)
             ws['wp'] = [ws['wp_all'][l] for l in range(L)]
             ws['gp'] = A.empty(2 * B * R * T * (L if self.skip_f16x3 else 1), dtype=torch.float16, device=dev)
@@ -568,6 +572,11 @@ class VQVAE:
         flag = self.x3_flag if gd else None
         WS = 1.0 if gd else 256.0          # guarded: the weight scale lives on the device (exact max-abs of this step's weights)
         head_x3 = ws['head_x3'] = bool(gd and self.head_x3 and 'hp' in ws and T % 32 == 0)
+        # layer l's input planes: kept per layer for the weight gradients where the skip contraction runs on the engine (then
+        # every layer hands its successor planes), else one buffer (slot L: the planes of net[L], which nothing reads)
+        keep_xp = bool('xp_all' in ws and f16x3_skip)
+        ws['xp_kept'] = keep_xp
+        xpl = (lambda l: ws['xp_all'][l]) if keep_xp else (lambda l: ws['xp'])    # noqa: E731
         # the guarded engine's gate backward forms tanh = gated / sigmoid itself: tanh is not stored (54 MB less per layer and gate
         # conv, 166 -> 157 us); VQW_SAVE_TANH=1 stores it
         drop_th = ws['th_dropped'] = bool(gd and self.gbwd_f16x3 and os.environ.get('VQW_SAVE_TANH', '0') != '1')
@@ -586,8 +595,8 @@ class VQVAE:
             K.f16x3_pack_weights(P['post1_w'], ws['wpost1'], S, S, S, 1.0, scale_dev=sc('WH'), mode=md)
             K.f16x3_pack_weights(P['post2_w'], ws['wpost2'], S, Q, Q, 1.0, scale_dev=sc('WH'), mode=md)
             # wavenet.py:53-54 on the first layer's input planes
-            K.f16x3_split_activations(net[0], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
-            K.f16x3_out_conv(xp=ws['xp'], Cin=R, wp=ws['wskip0'], bias=P['skip0_b'], net_out=ws['skip'], B=B, T=T, R=S, S=0,
+            K.f16x3_split_activations(net[0], xpl(0), B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
+            K.f16x3_out_conv(xp=xpl(0), Cin=R, wp=ws['wskip0'], bias=P['skip0_b'], net_out=ws['skip'], B=B, T=T, R=S, S=0,
                              w_scale_inv=1.0, x_scale=sc('X', 0), w_scale=sc('WH'), mode=md)
         else:
             K.conv_gemm(x0=net[0], w=P['skip0_w'], bias=P['skip0_b'], out0=ws['skip'], B=B, T_in=T, T_out=T, M=S,
@@ -602,8 +611,8 @@ class VQVAE:
         for l, d in enumerate(self.dil):
             if f16x3:
                 if (l == 0 and not head_x3) or not f16x3_out:
-                    K.f16x3_split_activations(net[l], ws['xp'], B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
-                K.f16x3_gate_conv(xp=ws['xp'], wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if (save and not drop_th) else None,
+                    K.f16x3_split_activations(net[l], xpl(l), B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
+                K.f16x3_gate_conv(xp=xpl(l), wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if (save and not drop_th) else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
                                   cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T=T, R=R, ks=self.ks,
                                   dilation=d, w_scale_inv=1.0 / WS, out_planes=ws['gp'] if f16x3_out else None,
@@ -611,12 +620,12 @@ class VQVAE:
                                   x_scale=sc('X', l), w_scale=sc('WG'), mode=md)
                 if f16x3_skip:   # residual half now; the skip half of all layers after the loop
                     K.f16x3_out_conv(xp=ws['gp'], xp_kc0=l * (R // 8), xp_KC=L * (R // 8), Cin=R, wp=ws['wres'][l],
-                                     bias=P['out_b'][l][S:], net_in=net[l], net_out=net[l + 1], net_out_planes=ws['xp'],
+                                     bias=P['out_b'][l][S:], net_in=net[l], net_out=net[l + 1], net_out_planes=xpl(l + 1),
                                      B=B, T=T, R=R, S=0, w_scale_inv=1.0 / WS, w_scale=sc('WO'), out_scale=sc('X', l + 1),
                                      out_amax=am('X', l + 1), flag=flag, mode=md)
                 elif f16x3_out:
                     K.f16x3_out_conv(xp=ws['gp'], wp=ws['wop'][l], bias=P['out_b'][l], skip=ws['skip'], net_in=net[l],
-                                     net_out=net[l + 1], net_out_planes=ws['xp'], B=B, T=T, R=R, S=S, w_scale_inv=1.0 / 256.0, mode=md)
+                                     net_out=net[l + 1], net_out_planes=xpl(l + 1), B=B, T=T, R=R, S=S, w_scale_inv=1.0 / 256.0, mode=md)
                 else:
                     K.conv_gemm(x0=ws['gated'][l], w=P['out_w'][l], bias=P['out_b'][l], out0=ws['skip'], out1=net[l + 1],
                                 aux1=net[l], B=B, T_in=T, T_out=T, M=S + R, M0=S, C0=R, taps=[0],
@@ -862,6 +871,10 @@ class VQVAE:
         # gradient reads its q operand from them (transposed LDS reads, vqw_f16x3_wgrad q_planes) and gate backward no longer
         # writes fp32 dpre at all (109 of its 312 MB per layer)
         qp = batched and os.environ.get('VQW_WGRAD_QP', '1') != '0'
+        # ... and so do p = the layer's input planes (kept per layer by the forward pass) and p = the gated planes of all layers
+        pp = batched and bool(ws.get('xp_kept'))
+        gated_p = (lambda i: dict(p_planes=ws['gp'], p_planes_kc0=i * (R // 8), p_planes_KC=L * (R // 8))) if pp else \
+            (lambda i: dict(p=ws['gated'][i]))
         if batched and 'dnet_all' not in ws:
             ws['dnet_all'] = [A.empty(B, R, T, device=self.dev) for _ in range(L)]       # dnet_all[l] = d loss / d net[l]
             ws['_poison'] += ws['dnet_all']
@@ -887,8 +900,9 @@ class VQVAE:
         def flush_gate(odd):
             layers, pend_gate[odd] = pend_gate[odd], []
             if layers:
-                probs = [dict(p=net[i], dw=G['gated_w'][i], taps=[-(ks - 1 - j) * self.dil[i] for j in range(ks)],
+                probs = [dict(dw=G['gated_w'][i], taps=[-(ks - 1 - j) * self.dil[i] for j in range(ks)],
                               p_scale=sc('X', i), q0_scale=sc('DP', i), q_seg=dce.view(-1)[i * 2 * R * Tz:],
+                              **(dict(p_planes=ws['xp_all'][i]) if pp else dict(p=net[i])),
                               **(dict(q_planes=ws['dp_all'][i], q_planes_scale=GS) if qp else dict(q0=ws['dpre_all'][i]))) for i in layers]
                 on_side(lambda: K.f16x3_wgrad_batch(probs, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=2 * R, seg_T=Tz, seg_bstride=cbs, mode=md))
 
@@ -896,16 +910,17 @@ class VQVAE:
             nonlocal pend_res
             layers, pend_res = pend_res, []
             if layers:         # (the top layer has no dnet: its residual kernel gets no gradient)
-                probs = [dict(p=ws['gated'][i], q0=ws['dnet_all'][i + 1], dw=G['out_w'][i].view(-1)[S:], q_total=G['out_b'][i][S:])
+                probs = [dict(q0=ws['dnet_all'][i + 1], dw=G['out_w'][i].view(-1)[S:], q_total=G['out_b'][i][S:], **gated_p(i))
                          for i in layers]
                 on_side(lambda: K.f16x3_wgrad_batch(probs, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=R, lddw=S + R, taps=[0],
                                                     q0_scale=sc('G'), total_cols=(0, R), mode=md))
 
-        if batched:      # the skip halves of all layers
+        if batched:      # the skip halves of all layers (dskip: the first S / 8 chunks of the gradient planes)
+            qsk = dict(q_planes=ws['gr'], q_planes_KC=(S + R) // 8, q_planes_scale=GS) if (qp and gbwd_x3) else dict(q0=dskip)
             for i0 in range(0, L, K.WGRAD_MAX_BATCH):
-                probs = [dict(p=ws['gated'][i], dw=G['out_w'][i].view(-1)) for i in range(i0, min(L, i0 + K.WGRAD_MAX_BATCH))]
-                on_side(lambda: K.f16x3_wgrad_batch(probs, q0=dskip, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=S, lddw=S + R, taps=[0],
-                                                    q0_scale=sc('G'), mode=md))
+                probs = [dict(dw=G['out_w'][i].view(-1), **gated_p(i)) for i in range(i0, min(L, i0 + K.WGRAD_MAX_BATCH))]
+                on_side(lambda: K.f16x3_wgrad_batch(probs, slab=ws['wslab'], B=B, T=T, Cp=R, Q0=S, lddw=S + R, taps=[0],
+                                                    q0_scale=sc('G'), mode=md, **qsk))
         side_done = {}
         dnet = dnet_ring[(L - 1) % 3]
         for l in range(L - 1, -1, -1):
