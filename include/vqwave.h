@@ -431,7 +431,10 @@ typedef struct vqw_f16x3_out_desc {
     int32_t cond_T;
     int32_t flags;         /* bit 0 (epi 2): planes hold relu(net_out).  bit 1 (epi 1): aux0 is the layer's gated OUTPUT tanh * sigmoid instead
                             * of tanh (a forward pass that does not store tanh: vqw_f16x3_gate_conv with save0 = NULL writes 54 MB less
-                            * per layer); the kernel forms tanh = aux0 / aux1, 0 where the sigmoid underflowed                       */
+                            * per layer); the kernel forms tanh = aux0 / aux1, 0 where the sigmoid underflowed.  bit 2 (epi 1): that gated
+                            * output is given as the PLANES vqw_f16x3_gate_conv wrote (aux0 = planes base, aux0_KC chunks per plane, this
+                            * layer's R / 8 chunks from aux0_kc0; scale 1): vqw_f16x3_gate_conv then needs no fp32 out0 at all             */
+    int32_t aux0_KC, aux0_kc0;
 } vqw_f16x3_out_desc;
 int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* d, vqw_stream_t s);
 

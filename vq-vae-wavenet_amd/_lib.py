@@ -74,6 +74,7 @@ class F16x3OutDesc(C.Structure):
         ('aux0', _fp), ('aux1', _fp),
         ('x_scale', _fp), ('w_scale', _fp), ('out_scale', _fp), ('out_amax', _fp), ('flag', _fp), ('mode', C.c_int32),
         ('cond', _fp), ('cond_bstride', C.c_int64), ('cond_T', C.c_int32), ('flags', C.c_int32),
+        ('aux0_KC', C.c_int32), ('aux0_kc0', C.c_int32),
     ]
 
 

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_f16x3_kernel(const 
                 addg[e][0] = (hb ? bgv : 0.0f) + (hc ? g0 : 0.0f); addg[e][1] = (hb ? bgv : 0.0f) + (hc ? g1 : 0.0f);
             }
             const size_t off = ((size_t)b * R + c0) * T + tcol;
-            float* po = d.out0 + off;
+            float* po = (d.out0 ? d.out0 : d.save1) + off;
             float* p0 = s0 ? d.save0 + off : po;
             float* p1 = s1 ? d.save1 + off : po;
             float gq[2][4];
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_f16x3_kernel(const 
                     gq[j][e] = th * sg;
                     if (s0) p0[o] = th;
                     if (s1) p1[o] = sg;
-                    po[o] = gq[j][e];
+                    if (d.out0) po[o] = gq[j][e];        // (optional where every reader takes the planes: 54 MB less per layer)
                 }
             if (d.out_planes) {
 #pragma unroll
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void head_f16x3_kernel(const 
 // Gate backward (the transpose of gated_cnn's tanh * sigmoid, wavenet_ops.py:112-113, behind the transposed 1x1 convs):
 // dg = W_out^T [dskip; dnet] over the gradient planes (dskip in chunks 0..S/8-1, dnet behind it), then
 // dpre[filter c] = dg * sg * (1 - th^2), dpre[gate c] = dg * th * sg * (1 - sg); dpre also as planes for the input gradient.
-template <bool BF, int MR, bool FG = false>      // FG: aux0 holds tanh * sigmoid instead of tanh
+template <bool BF, int MR, int FG = 0>      // FG 1: aux0 holds tanh * sigmoid instead of tanh; 2: ... as the gated PLANES of the forward pass
 __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
@@ -741,16 +741,43 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
             float* pf = d.net_out + offo;
             float* pq = pf + (size_t)R * T;
             float th[2][4], sg[2][4], qf[2][4], qg[2][4];
+            if constexpr (FG == 2) {
+                // this lane's four channels of one (batch, time) row = 8 bytes of the row's plane entry (store_plane_quad's layout)
+                const int AKC = d.aux0_KC > 0 ? d.aux0_KC : R / 8;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const char* pe = reinterpret_cast<const char*>(d.aux0) + ((size_t)(d.aux0_kc0 + c0 / 8) * a.NB + n0 + 64 * wv + 32 * j + l31) * 16 + lhi * 8;
+                    const uint2 h1 = *reinterpret_cast<const uint2*>(pe);
+                    const unsigned w1[2] = {h1.x, h1.y};
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) th[j][e] = __uint_as_float((e & 1) ? (w1[e >> 1] & 0xffff0000u) : (w1[e >> 1] << 16));
+                    } else {
+                        const uint2 h2 = *reinterpret_cast<const uint2*>(pe + (size_t)AKC * a.NB * 16);
+                        const unsigned w2[2] = {h2.x, h2.y};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const u16 a1 = (u16)((e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu)), a2 = (u16)((e & 1) ? (w2[e >> 1] >> 16) : (w2[e >> 1] & 0xffffu));
+                            th[j][e] = (float)__builtin_bit_cast(_Float16, a1) + (float)__builtin_bit_cast(_Float16, a2);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sg[j][e] = pg[e * T + 32 * j];
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { th[j][e] = pt[e * T + 32 * j]; sg[j][e] = pg[e * T + 32 * j]; }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const float dg = acc[i][j][v4 * 4 + e] * winv;
-                    if constexpr (FG) {
+                    if constexpr (FG != 0) {
                         // th[][] holds g = tanh * sigmoid (the forward pass did not store tanh):
                         //   sg (1 - tanh^2) = sg - g^2 / sg  (0 where the sigmoid underflowed),   tanh sg (1 - sg) = g (1 - sg)
                         const float g_ = th[j][e], sv = sg[j][e];
@@ -1466,9 +1493,13 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     }
     if (bwd) VQW_CHECK(d.S == 0 && d.R > 0 && d.aux0 && d.aux1 && d.Cin > 0, "vqw_f16x3_out_conv: gate backward needs S = 0, saved tanh (aux0) and sigmoid (aux1), Cin");
     kfn_t kfn = (bwd ? kbwds : kouts)[(bf ? 1 : 0) + (half ? 2 : 0)];
-    if (bwd && (d.flags & 2)) {
-        VQW_CHECK(!bf, "vqw_f16x3_out_conv: gate backward from the gated output (flags bit 1) exists in the fp16x3 mode only");
-        kfn = half ? gate_bwd_f16x3_kernel<false, 4, true> : gate_bwd_f16x3_kernel<false, 8, true>;
+    if (bwd && (d.flags & 6)) {
+        const bool pl = (d.flags & 4) != 0;      // bit 2: aux0 = the gated planes [planes][aux0_KC][B*T][8] from chunk aux0_kc0
+        VQW_CHECK(!bf || pl, "vqw_f16x3_out_conv: gate backward from the fp32 gated output (flags bit 1) exists in the fp16x3 mode only");
+        VQW_CHECK(!pl || (d.aux0_kc0 >= 0 && d.aux0_kc0 + d.R / 8 <= (d.aux0_KC > 0 ? d.aux0_KC : d.R / 8)), "vqw_f16x3_out_conv: bad chunk range of the gated planes");
+        const kfn_t kg[6] = {gate_bwd_f16x3_kernel<false, 8, 1>, gate_bwd_f16x3_kernel<false, 4, 1>, gate_bwd_f16x3_kernel<false, 8, 2>,
+                             gate_bwd_f16x3_kernel<false, 4, 2>, gate_bwd_f16x3_kernel<true, 8, 2>, gate_bwd_f16x3_kernel<true, 4, 2>};
+        kfn = kg[(pl ? (bf ? 4 : 2) : 0) + (half ? 1 : 0)];
     }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", lds);
@@ -1482,7 +1513,7 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* dp, vqw_stream_t s_) {
     hipStream_t st = (hipStream_t)s_;
     VQW_CHECK(dp, "vqw_f16x3_gate_conv: null descriptor");
     const vqw_f16x3_gate_desc& d = *dp;
-    VQW_CHECK(d.xp && d.wp && d.out0, "vqw_f16x3_gate_conv: null operand");
+    VQW_CHECK(d.xp && d.wp && (d.out0 || (d.out_planes && d.save1)), "vqw_f16x3_gate_conv: null operand (out0 may be NULL only with out_planes and save1)");
     VQW_CHECK(d.B > 0 && d.T > 0 && d.T % 256 == 0, "vqw_f16x3_gate_conv: T must be a positive multiple of 256 (got %d)", d.T);
     VQW_CHECK(d.R > 0 && d.R % 128 == 0, "vqw_f16x3_gate_conv: R must be a multiple of 128 (got %d)", d.R);
     VQW_CHECK(d.ks >= 1 && d.ks <= 8 && d.dilation >= 1, "vqw_f16x3_gate_conv: bad kernel size %d / dilation %d", d.ks, d.dilation);

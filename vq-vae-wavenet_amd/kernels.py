@@ -292,7 +292,7 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
                    net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
                    planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None, x_scale=None, w_scale=None,
                    out_scale=None, out_amax=None, flag=None, mode=None, cond=None, cond_T=0, cond_bstride=0, relu_planes=False,
-                   aux0_is_gated=False):
+                   aux0_is_gated=False, aux0_planes=None, aux0_KC=0, aux0_kc0=0):
     """vqw_f16x3_out_conv; epi 0: skip rows += / residual rows = net_in + W x + b; epi 1: gate backward; epi 2: the 1x1 convs
     around the stack: net_out = (aux0 > 0) * (net_in + W x + bias + cond), planes of net_out or relu(net_out)."""
     mode = x3_mode(mode)
@@ -308,7 +308,10 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
         if not (epi == 1 and net_out is None and net_out_planes is not None):     # (gate backward may write planes only)
             _need(net_out, B * R * T * (2 if epi == 1 else 1), 'net_out')
     if epi == 1:
-        _need(aux0, B * R * T, 'aux0')
+        if aux0_planes is not None:      # the gated planes of the forward pass instead of fp32 tanh / gated
+            _need_planes(aux0_planes, (1 if mode & X3_BF16 else 2) * (aux0_KC or R // 8) * 8 * B * T, 'aux0_planes')
+        else:
+            _need(aux0, B * R * T, 'aux0')
         _need(aux1, B * R * T, 'aux1')
     if epi == 2 and aux0 is not None:
         _need(aux0, B * R * T, 'aux0')
@@ -328,6 +331,8 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     d.ks, d.dilation, d.dir = ks, dilation, direction
     d.planes_kc0, d.planes_KC, d.plane_scale, d.epi = planes_kc0, planes_KC, float(plane_scale), epi
     d.aux0 = None if aux0 is None else aux0.data_ptr()
+    if aux0_planes is not None:
+        d.aux0, d.aux0_KC, d.aux0_kc0 = aux0_planes.data_ptr(), aux0_KC, aux0_kc0
     d.aux1 = None if aux1 is None else aux1.data_ptr()
     d.w_scale_inv = float(w_scale_inv)
     d.x_scale, d.w_scale, d.out_scale = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale'), _slot(out_scale, 'out_scale')
@@ -336,7 +341,7 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
     if cond is not None:
         _need(cond, (B - 1) * cond_bstride + R * cond_T, 'cond')
         d.cond, d.cond_T, d.cond_bstride = cond.data_ptr(), cond_T, cond_bstride
-    d.flags = (1 if relu_planes else 0) | (2 if aux0_is_gated else 0)
+    d.flags = (1 if relu_planes else 0) | (2 if aux0_is_gated else 0) | (4 if aux0_planes is not None else 0)
     L.check(L.lib().vqw_f16x3_out_conv(C.byref(d), L.stream()))
 
 
@@ -373,7 +378,8 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     mode = x3_mode(mode)
     _need_planes(xp, 2 * B * R * T, 'xp')
     _need_planes(wp, 2 * ks * R * 2 * R, 'wp')
-    _need(out0, B * R * T, 'out0')
+    if out0 is not None or out_planes is None or save1 is None:       # (out0 may be left out where every reader takes the planes)
+        _need(out0, B * R * T, 'out0')
     for t, nm in ((save0, 'save0'), (save1, 'save1')):
         if t is not None:
             _need(t, B * R * T, nm)
@@ -387,7 +393,7 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
     d.xp, d.wp = xp.data_ptr(), wp.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
     d.cond = None if cond is None else cond.data_ptr()
-    d.out0 = out0.data_ptr()
+    d.out0 = None if out0 is None else out0.data_ptr()
     d.save0 = None if save0 is None else save0.data_ptr()
     d.save1 = None if save1 is None else save1.data_ptr()
     if out_planes is not None:

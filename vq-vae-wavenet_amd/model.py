@@ -580,6 +580,10 @@ class VQVAE:
         # the guarded engine's gate backward forms tanh = gated / sigmoid itself: tanh is not stored (54 MB less per layer and gate
         # conv, 166 -> 157 us); VQW_SAVE_TANH=1 stores it
         drop_th = ws['th_dropped'] = bool(gd and self.gbwd_f16x3 and os.environ.get('VQW_SAVE_TANH', '0') != '1')
+        # ... and then nothing reads the fp32 gated output either (gate backward and the 1x1 kernels' weight gradients take the
+        # gated planes): the gate conv does not write it (54 MB less per layer)
+        drop_g = ws['gated_dropped'] = bool(keep_xp and save and drop_th and os.environ.get('VQW_WGRAD_BATCH', '1') != '0'
+                                            and os.environ.get('VQW_SAVE_GATED', '0') != '1')
         if gd:
             K.f16x3_amax(P['gated_w'], am('WG'), flag=flag)
             K.f16x3_amax(P['out_w'], am('WO'), flag=flag)
@@ -612,7 +616,8 @@ class VQVAE:
             if f16x3:
                 if (l == 0 and not head_x3) or not f16x3_out:
                     K.f16x3_split_activations(net[l], xpl(l), B, R, T, scale_dev=sc('X', 0), flag=flag, mode=md)
-                K.f16x3_gate_conv(xp=xpl(l), wp=ws['wp'][l], out0=ws['gated'][l], save0=ws['th'][l] if (save and not drop_th) else None,
+                K.f16x3_gate_conv(xp=xpl(l), wp=ws['wp'][l], out0=None if drop_g else ws['gated'][l],
+                                  save0=ws['th'][l] if (save and not drop_th) else None,
                                   save1=ws['sg'][l] if save else None, bias=P['gated_b'][l],
                                   cond=ce_flat[l * 2 * R * Tz:], cond_T=Tz, cond_bstride=cbs, B=B, T=T, R=R, ks=self.ks,
                                   dilation=d, w_scale_inv=1.0 / WS, out_planes=ws['gp'] if f16x3_out else None,
@@ -873,6 +878,9 @@ class VQVAE:
         qp = batched and os.environ.get('VQW_WGRAD_QP', '1') != '0'
         # ... and so do p = the layer's input planes (kept per layer by the forward pass) and p = the gated planes of all layers
         pp = batched and bool(ws.get('xp_kept'))
+        g_dropped = bool(ws.get('gated_dropped'))
+        if g_dropped and not (pp and gbwd_x3):
+            raise RuntimeError('the forward pass did not store the fp32 gated output but the backward pass needs it')
         gated_p = (lambda i: dict(p_planes=ws['gp'], p_planes_kc0=i * (R // 8), p_planes_KC=L * (R // 8))) if pp else \
             (lambda i: dict(p=ws['gated'][i]))
         if batched and 'dnet_all' not in ws:
@@ -933,7 +941,8 @@ class VQVAE:
                 main.wait_event(side_done[l + 2])            # dpre[l % 2] and dnet[(l - 1) % 3] are free again
             if gbwd_x3:
                 K.f16x3_out_conv(epi=1, xp=ws['gr'], Cin=S if top else S + R, xp_KC=(S + R) // 8,
-                                 wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=ws['gated'][l] if th_dropped else ws['th'][l],
+                                 wp=ws['wgb_top'] if top else ws['wgb'][l], aux0=None if g_dropped else (ws['gated'][l] if th_dropped else ws['th'][l]),
+                                 aux0_planes=ws['gp'] if g_dropped else None, aux0_KC=L * (R // 8), aux0_kc0=l * (R // 8),
                                  aux0_is_gated=th_dropped, aux1=ws['sg'][l], net_out=dpre,
                                  net_out_planes=dplanes, plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (WS * GS),
                                  x_scale=sc('G'), w_scale=sc('WO'), out_scale=sc('DP', l), out_amax=am('DP', l), flag=flag, mode=md)
