@@ -748,18 +748,16 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
                 for (int j = 0; j < 2; ++j) {
                     const char* pe = reinterpret_cast<const char*>(d.aux0) + ((size_t)(d.aux0_kc0 + c0 / 8) * a.NB + n0 + 64 * wv + 32 * j + l31) * 16 + lhi * 8;
                     const uint2 h1 = *reinterpret_cast<const uint2*>(pe);
-                    const unsigned w1[2] = {h1.x, h1.y};
+                    // (no local arrays here: indexed ones kept the 256-row instantiation from unrolling and put the accumulators in scratch)
                     if constexpr (BF) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) th[j][e] = __uint_as_float((e & 1) ? (w1[e >> 1] & 0xffff0000u) : (w1[e >> 1] << 16));
+                        th[j][0] = __uint_as_float(h1.x << 16); th[j][1] = __uint_as_float(h1.x & 0xffff0000u);
+                        th[j][2] = __uint_as_float(h1.y << 16); th[j][3] = __uint_as_float(h1.y & 0xffff0000u);
                     } else {
                         const uint2 h2 = *reinterpret_cast<const uint2*>(pe + (size_t)AKC * a.NB * 16);
-                        const unsigned w2[2] = {h2.x, h2.y};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const u16 a1 = (u16)((e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu)), a2 = (u16)((e & 1) ? (w2[e >> 1] >> 16) : (w2[e >> 1] & 0xffffu));
-                            th[j][e] = (float)__builtin_bit_cast(_Float16, a1) + (float)__builtin_bit_cast(_Float16, a2);
-                        }
+                        auto lo16 = [](unsigned w) { return (float)__builtin_bit_cast(_Float16, (u16)(w & 0xffffu)); };
+                        auto hi16 = [](unsigned w) { return (float)__builtin_bit_cast(_Float16, (u16)(w >> 16)); };
+                        th[j][0] = lo16(h1.x) + lo16(h2.x); th[j][1] = hi16(h1.x) + hi16(h2.x);
+                        th[j][2] = lo16(h1.y) + lo16(h2.y); th[j][3] = hi16(h1.y) + hi16(h2.y);
                     }
                 }
 #pragma unroll
@@ -899,6 +897,7 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
             }
     } else {
         g.xKC = d.Cin / 8; g.tjstep = 2; g.tsgn = 1; g.ts2d = 0;
+#pragma unroll 1
         for (int r = 0; r < 2; ++r) {
             g.tj0 = (r + d.pad_left) & 1; g.toff = r + d.pad_left;
             g.ks = (d.ks - g.tj0 + 1) / 2;                       // taps of this parity (>= 1 for ks >= 2)
