@@ -487,7 +487,7 @@ def main():
             rec["roofline"].update({"kernel": "gate_f16x3_kernel<%d-row blocks> (dilated k=3 conv 256->512 + cond-add + tanh*sigmoid gate; operands as two fp16 planes, 3 MFMA terms)" % (128 if model.x3_mode_fwd & 2 else 256),
                                     "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "frac": ach / PEAK_F16_MFMA_TFLOPS,
                                     "pipe_utilisation": 3 * ach / PEAK_F16_MFMA_TFLOPS, "mfma_terms_per_product": 3,
-                                    "traffic": hbm_traffic('round2_gate_f16x3_traffic.json' if model.x3_mode_fwd & 2 else 'round2_gate_f16x3_traffic_256row_blocks.json'),
+                                    "traffic": hbm_traffic('round3_gate_f16x3_traffic.json' if model.x3_mode_fwd & 2 else 'round2_gate_f16x3_traffic_256row_blocks.json'),
                                     "whole_step_frac": step_tflops / PEAK_F16_MFMA_TFLOPS})
             rec["roofline_wgrad"] = wgrad_line(wg_n, wg_ms, wg_flop, PEAK_F16_MFMA_TFLOPS,
                                                "wgrad_f16x3_kernel (all engine weight-gradient launches of the step: decoder, convs around the stack, "
