@@ -490,8 +490,9 @@ def main():
                                     "traffic": hbm_traffic('round3_gate_f16x3_traffic.json' if model.x3_mode_fwd & 2 else 'round2_gate_f16x3_traffic_256row_blocks.json'),
                                     "whole_step_frac": step_tflops / PEAK_F16_MFMA_TFLOPS})
             rec["roofline_wgrad"] = wgrad_line(wg_n, wg_ms, wg_flop, PEAK_F16_MFMA_TFLOPS,
-                                               "wgrad_f16x3_kernel (all engine weight-gradient launches of the step: decoder, convs around the stack, "
-                                               "encoder layers 1-5; slab reduction inside the kernel) + the 2 fp32-engine launches")
+                                               "wgrad_f16x3_kernel + wgrad_reduce_kernel (every engine weight-gradient launch of the step: the decoder's "
+                                               "layers in batches -- all skip halves, gate kernels by six, residual halves -- with both operands read as "
+                                               "planes, the convs around the stack, encoder layers 1-5) + the 2 fp32-engine launches")
             if rec["roofline_wgrad"]:
                 rec["roofline_wgrad"]["pipe_utilisation"] = 3 * rec["roofline_wgrad"]["frac"]
             rec["engine"] = {"name": "f16x3", "steps_on_engine": model.x3_steps, "steps_repeated_on_fp32": model.x3_fallbacks}

@@ -512,6 +512,11 @@ typedef struct vqw_f16x3_wgrad_desc {
     int32_t p_planes_KC;    /* 0 = Cp / 8 */
     int32_t p_planes_kc0;
     float p_planes_scale;
+    /* with p_planes: tap j reads rows t + tap_shift[j] (either sign; outside [0, T) = zero padding) of the chunks starting at
+     * p_planes_kc0 + p_tap_chunk[j].  The weight gradient of a STRIDE-2 conv (encoder.py:17-18) over the space-to-depth planes of its
+     * input (vqw_f16x3_split_activations VQW_X3_S2D, T = output length): tap j with e = j - pad_left has
+     * p_tap_chunk[j] = (e & 1) * Cp / 8 and tap_shift[j] = e >> 1 -- no p_stride 2, no single-float requests.                    */
+    int32_t p_tap_chunk[VQW_MAX_TAPS];
 } vqw_f16x3_wgrad_desc;
 int vqw_f16x3_wgrad(const vqw_f16x3_wgrad_desc* d, vqw_stream_t s);
 /* `n` (<= 32) weight gradients of ONE shape in one launch -- the same kernels of several layers: d[i] may differ in p, q0, q1, dw,

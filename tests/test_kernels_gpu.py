@@ -607,6 +607,18 @@ def test_wgrad_f16x3_stride2_matches_fp64(K, B, Tq, Tin, pl, scaled):
         assert err <= 2e-6 * upd + 1e-6 * dw0.abs().max().item(), 'max err %.3e of update %.3e' % (err, upd)
     want_tot = tot0.double() + q.double().sum((0, 2))
     assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item() + 2e-6 * tot0.abs().max().item()
+    # the same gradient over the space-to-depth planes of p (what the forward conv reads) and the planes of q (what the input gradient
+    # reads): tap j with e = j - pl is parity block e & 1 at row offset e >> 1 -- the same fp16 pieces, hence the same bits
+    if Tin == 2 * Tq and Tq % 32 == 0:
+        pp = torch.empty(2 * B * Cp * Tin, dtype=torch.float16, device=DEV)
+        qp = torch.empty(2 * B * Q0 * Tq, dtype=torch.float16, device=DEV)
+        K.f16x3_split_activations(p, pp, B, Cp, Tin, scale_dev=sc[0:1], mode=K.X3_S2D)
+        K.f16x3_split_activations(q, qp, B, Q0, Tq, scale_dev=sc[1:2])
+        dw2, tot2 = dw0.clone(), tot0.clone()
+        K.f16x3_wgrad(p_planes=pp, p_planes_KC=2 * Cp // 8, p_tap_chunk=[((j - pl) & 1) * (Cp // 8) for j in range(5)], q_planes=qp, dw=dw2,
+                      slab=slab, B=B, T=Tq, Cp=Cp, Q0=Q0, taps=[(j - pl) >> 1 for j in range(5)], p_scale=sc[0:1], q0_scale=sc[1:2], q_total=tot2)
+        assert torch.equal(dw2, got), 'strided weight gradient from planes differs from the fp32-operand launch'
+        assert (tot2.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item() + 2e-6 * tot0.abs().max().item()
 
 
 @pytest.mark.parametrize('B,Tout,Cin,M', [(2, 128, 128, 128), (1, 256, 128, 256), (8, 96, 128, 128), (3, 104, 128, 128), (8, 1664, 768, 768)])
@@ -816,12 +828,15 @@ def test_wgrad_f16x3_batch_of_layers_in_one_launch(K):
         for qp in (False, True):
             dws = [torch.zeros(3, R, 2 * R, device=DEV) for _ in dils]
             segs = [torch.zeros(B, 2 * R, Tz, device=DEV) for _ in dils]
+            tots = [torch.zeros(2 * R, device=DEV) for _ in dils]
             probs = [dict(p=nets[i], dw=dws[i], taps=[-2 * d, -d, 0], p_scale=scales[i:i + 1], q0_scale=scales[5 + i:6 + i], q_seg=segs[i],
-                          **(dict(q_planes=planes[i]) if qp else dict(q0=dpres[i]))) for i, d in enumerate(dils)]
+                          q_total=tots[i], **(dict(q_planes=planes[i]) if qp else dict(q0=dpres[i]))) for i, d in enumerate(dils)]
             K.f16x3_wgrad_batch(probs, slab=slab, B=B, T=T, Cp=R, Q0=2 * R, seg_T=Tz, mode=md)
-            res[qp] = (dws, segs)
+            res[qp] = (dws, segs, tots)
         for i in range(len(dils)):
             assert torch.equal(res[True][0][i], res[False][0][i]), 'q from planes: dW of layer %d differs (bf16=%s)' % (i, bf)
+            for qp in (False, True):
+                close(res[qp][2][i], dpres[i].sum((0, 2)), rtol=3e-3 if bf else 1e-4, atol=3e-3 if bf else 1e-6, what='bias sums (q planes: %s), layer %d' % (qp, i))
             close(res[True][1][i], dpres[i].view(B, 2 * R, Tz, T // Tz).sum(-1), rtol=3e-3 if bf else 1e-4, atol=3e-3 if bf else 1e-4,
                   what='condition sums from planes, layer %d' % i)
     # odd dilations (unaligned windows of p) with q from planes

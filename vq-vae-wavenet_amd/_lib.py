@@ -97,6 +97,7 @@ class F16x3WgradDesc(C.Structure):
         ('total_o1', C.c_int32), ('mode', C.c_int32), ('p_relu', C.c_int32), ('p_stride', C.c_int32), ('Tp', C.c_int32), ('xcd_group', C.c_int32),
         ('q_planes', _fp), ('q_planes_KC', C.c_int32), ('q_planes_kc0', C.c_int32), ('q_planes_scale', C.c_float),
         ('p_planes', _fp), ('p_planes_KC', C.c_int32), ('p_planes_kc0', C.c_int32), ('p_planes_scale', C.c_float),
+        ('p_tap_chunk', C.c_int32 * MAX_TAPS),
     ]
 
 

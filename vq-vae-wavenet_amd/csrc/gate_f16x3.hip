@@ -957,6 +957,7 @@ struct WgProblem {
     const void* pp;       // PP kernels: p as operand planes, likewise
     int p_KC, p_kc0;
     float p_hscale;
+    int pkoff[VQW_MAX_TAPS];   // PP: chunk offset of tap j's rows (space-to-depth planes of a stride-2 conv's input: the parity block)
     int shift[VQW_MAX_TAPS];
 };
 struct WgArgs {
@@ -1058,7 +1059,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     const unsigned qspan = (unsigned)(32 * NBq * 16 < 0x7fffffffull ? 32 * NBq * 16 : 0x7fffffffull);
     const __amdgpu_buffer_rsrc_t rqp0 = vqw_make_rsrc(qpb, qspan);
     const __amdgpu_buffer_rsrc_t rqp1 = vqw_make_rsrc(qpb + (QP && !BF ? (size_t)pr.q_KC * NBq * 16 : 0), qspan);
-    const char* ppb = reinterpret_cast<const char*>(pr.pp) + (PP ? ((size_t)pr.p_kc0 + c0 / 8) * NBq * 16 : 0);
+    const char* ppb = reinterpret_cast<const char*>(pr.pp) + (PP ? ((size_t)pr.p_kc0 + pr.pkoff[tap] + c0 / 8) * NBq * 16 : 0);
     const __amdgpu_buffer_rsrc_t rpp0 = vqw_make_rsrc(ppb, qspan);
     const __amdgpu_buffer_rsrc_t rpp1 = vqw_make_rsrc(ppb + (PP && !BF ? (size_t)pr.p_KC * NBq * 16 : 0), qspan);
     float* const q_total = pr.q_total;
@@ -1090,7 +1091,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
         if constexpr (PP) {      // the same item geometry as QP; the tap's shift is a row offset, rows before the batch row read as zero
             if (n < 4 * NPL) {
                 const int chunk = (n & 3) * 8 + (lane & 7), tt = pt0 + 8 * wv + (lane >> 3) + shift;
-                const int off = tt >= 0 ? (int)(((size_t)chunk * NBq + (size_t)pb * T + tt) * 16) : (int)0x80000000;
+                // (tt >= T: only with the positive row shifts of a stride-2 conv's taps -- its right zero padding)
+                const int off = (tt >= 0 && tt < T) ? (int)(((size_t)chunk * NBq + (size_t)pb * T + tt) * 16) : (int)0x80000000;
                 rgp[n] = vqw_buf_load4((n >> 2) ? rpp1 : rpp0, off, 0);
             }
             return;
@@ -1341,9 +1343,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
     if (do_sum && q_total) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float both = qs_tot[h] + __shfl_xor(qs_tot[h], 1, 64);
-            const int row = o0 + (wv * 2 + h) * 32 + rsub;
-            if (hsel == 0 && row >= a.total_o0 && row < a.total_o1) unsafeAtomicAdd(q_total + row, both);
+            const float both = qs_tot[h] + __shfl_xor(qs_tot[h], QP ? 32 : 1, 64);
+            const int row = o0 + (wv * 2 + h) * 32 + (QP ? l31 : rsub);
+            if ((QP ? lhi == 0 : hsel == 0) && row >= a.total_o0 && row < a.total_o1) unsafeAtomicAdd(q_total + row, both);
         }
     }
     // ---- partial tile -> slab [tile][split][256][256], rows c, columns o (32 lanes = 128 contiguous bytes)
@@ -1618,7 +1620,9 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
                   "vqw_f16x3_wgrad_batch: an operand as planes in every problem or in none");
         if (e.p_planes) {
             const int kc = e.p_planes_KC > 0 ? e.p_planes_KC : d.Cp / 8;
-            VQW_CHECK(e.p_planes_kc0 >= 0 && e.p_planes_kc0 + d.Cp / 8 <= kc, "vqw_f16x3_wgrad: bad chunk range of the p planes (kc0=%d KC=%d)", e.p_planes_kc0, kc);
+            for (int j = 0; j < d.ntaps; ++j)
+                VQW_CHECK(e.p_planes_kc0 >= 0 && e.p_tap_chunk[j] >= 0 && e.p_planes_kc0 + e.p_tap_chunk[j] + d.Cp / 8 <= kc,
+                          "vqw_f16x3_wgrad: bad chunk range of the p planes (kc0=%d tap %d chunk offset %d KC=%d)", e.p_planes_kc0, j, e.p_tap_chunk[j], kc);
         }
         if (e.q_planes) {
             const int kc = e.q_planes_KC > 0 ? e.q_planes_KC : d.Q0 / 8;
@@ -1633,9 +1637,10 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
         q.pp = e.p_planes; q.p_KC = e.p_planes_KC > 0 ? e.p_planes_KC : d.Cp / 8; q.p_kc0 = e.p_planes_kc0;
         q.p_hscale = e.p_planes_scale > 0.0f ? e.p_planes_scale : 1.0f;
         for (int j = 0; j < d.ntaps; ++j) {
-            VQW_CHECK((s2 ? e.tap_shift[j] < (1 << 24) : e.tap_shift[j] <= 0) && e.tap_shift[j] > -(1 << 24),
-                      "vqw_f16x3_wgrad: tap shifts must be <= 0 unless p_stride is 2 (problem %d, tap %d: %d)", i, j, e.tap_shift[j]);
+            VQW_CHECK(((s2 || e.p_planes) ? e.tap_shift[j] < (1 << 24) : e.tap_shift[j] <= 0) && e.tap_shift[j] > -(1 << 24),
+                      "vqw_f16x3_wgrad: tap shifts must be <= 0 unless p_stride is 2 or p comes as planes (problem %d, tap %d: %d)", i, j, e.tap_shift[j]);
             q.shift[j] = e.tap_shift[j];
+            q.pkoff[j] = e.p_planes ? e.p_tap_chunk[j] : 0;
             odd |= (e.tap_shift[j] & 3) != 0;
         }
     }

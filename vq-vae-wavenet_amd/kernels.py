@@ -411,7 +411,7 @@ def f16x3_gate_conv(*, xp, wp, out0, B, T, R, ks, dilation, w_scale_inv, bias=No
 def _wgrad_desc(d, *, dw, slab, B, T, Cp, Q0, taps, p=None, q0=None, q1=None, Q1=0, lddw=None, dw_tap_stride=None, nsplit=0, p_scale=None,
                 q0_scale=None, q1_scale=None, q_total=None, total_cols=None, q_seg=None, seg_T=0, seg_bstride=0, mode=None,
                 p_stride=1, T_p=None, p_relu=False, q_planes=None, q_planes_KC=0, q_planes_kc0=0, q_planes_scale=0.0,
-                p_planes=None, p_planes_KC=0, p_planes_kc0=0, p_planes_scale=0.0):
+                p_planes=None, p_planes_KC=0, p_planes_kc0=0, p_planes_scale=0.0, p_tap_chunk=None):
     """q_planes: q0 as operand planes [planes][q_planes_KC or Q0/8 chunks][B*T][8] (scaled by q0_scale) instead of fp32."""
     mode = x3_mode(mode)
     T_p = T if T_p is None else T_p
@@ -420,6 +420,8 @@ def _wgrad_desc(d, *, dw, slab, B, T, Cp, Q0, taps, p=None, q0=None, q1=None, Q1
     if p_planes is not None:
         _need_planes(p_planes, (1 if mode & X3_BF16 else 2) * (p_planes_KC or Cp // 8) * 8 * B * T, 'p_planes')
         d.p_planes, d.p_planes_KC, d.p_planes_kc0, d.p_planes_scale = p_planes.data_ptr(), p_planes_KC, p_planes_kc0, float(p_planes_scale)
+        for j, kc in enumerate(p_tap_chunk or ()):       # (space-to-depth planes of a stride-2 conv's input: the tap's parity block)
+            d.p_tap_chunk[j] = int(kc)
     else:
         _need(p, B * Cp * T_p, 'p')
     if q_planes is not None:

@@ -366,6 +366,10 @@ class VQVAE:
                 ws['enc_scale'] = torch.ones(12, device=dev)
                 if train:
                     ws['ewtp'] = A.empty(5, 2 * 5 * F * F, dtype=torch.float16, device=dev)
+                    if self.wg_planes:     # the planes of each layer's input (space-to-depth) and output gradient are KEPT: the strided weight
+                        # gradients read them (p_planes / q_planes) instead of fetching fp32 one float per request (240 MB at B = 8)
+                        ws['esp'] = {i: A.empty(2 * B * F * ws['Tl'][i - 1], dtype=torch.float16, device=dev) for i in range(1, 6)}
+                        ws['edp'] = {i: A.empty(2 * B * F * ws['Tl'][i], dtype=torch.float16, device=dev) for i in range(1, 6)}
             if train:
                 ws['r'] = [e(B, F, t) for t in ws['Tl']]      # relu outputs
                 ws['y6'] = e(B, D, Tz)
@@ -465,8 +469,9 @@ class VQVAE:
             if i in ex3:
                 K.f16x3_amax(ws['X'][i - 1], ea[i:i + 1], flag=flag)
                 K.f16x3_update_scales(ea[i:i + 1], es[i:i + 1], target_exp=13, flag=flag)
-                K.f16x3_split_activations(ws['X'][i - 1], ws['eplanes'], B, F, Tin, scale_dev=es[i:i + 1], mode=K.X3_S2D)
-                K.f16x3_strided_conv(xp=ws['eplanes'], wp=ws['ewp'][i - 1], out=ws['X'][i], save_r=ws['r'][i] if save else None,
+                epl = ws['esp'][i] if (save and 'esp' in ws) else ws['eplanes']
+                K.f16x3_split_activations(ws['X'][i - 1], epl, B, F, Tin, scale_dev=es[i:i + 1], mode=K.X3_S2D)
+                K.f16x3_strided_conv(xp=epl, wp=ws['ewp'][i - 1], out=ws['X'][i], save_r=ws['r'][i] if save else None,
                                      B=B, T=Tout, Cin=F, M=F, ks=5, pad_left=pl, bias=P['enc_b'][i], bn_scale=sc[i * F:(i + 1) * F],
                                      bn_shift=sh[i * F:(i + 1) * F], relu=True, x_scale=es[i:i + 1], w_scale=es[0:1])
             elif nsplit > 1:
@@ -1094,10 +1099,23 @@ class VQVAE:
             if side is not main:
                 ready = torch.cuda.Event()
                 ready.record(main)
+            # both operands as planes where the forward conv ran on the engine (its space-to-depth input planes were kept) and the
+            # K pairs are whole (T_out % 32): tap j, e = j - pad_left, is parity block e & 1 at row offset e >> 1
+            w_planes = on_w and on_c and 'esp' in ws and Ti % 32 == 0
+            if w_planes:     # (the split the input gradient needs anyway, into this layer's own buffer, BEFORE the weight gradient)
+                K.f16x3_split_activations(dX, ws['edp'][i], B, F, Ti, scale_dev=es[5 + i:6 + i], mode=0)
+                if side is not main:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
             with torch.cuda.stream(side):                            # weight / bias gradients: nothing downstream waits
                 if side is not main:
                     side.wait_event(ready)
-                if on_w:
+                if w_planes:
+                    K.f16x3_wgrad(p_planes=ws['esp'][i], p_planes_KC=2 * F // 8, p_tap_chunk=[((j - pl) & 1) * (F // 8) for j in range(5)],
+                                  q_planes=ws['edp'][i], dw=G['enc_w'][i - 1], slab=ws['wslab'], B=B, T=Ti, Cp=F, Q0=F,
+                                  taps=[(j - pl) >> 1 for j in range(5)], p_scale=es[i:i + 1], q0_scale=es[5 + i:6 + i],
+                                  q_total=G['enc_b'][i], mode=0)
+                elif on_w:
                     K.f16x3_wgrad(p=ws['X'][i - 1], q0=dX, dw=G['enc_w'][i - 1], slab=ws['wslab'], B=B, T=Ti, Cp=F, Q0=F,
                                   taps=[j - pl for j in range(5)], p_scale=es[i:i + 1], q0_scale=es[5 + i:6 + i], p_stride=2, T_p=Tin,
                                   q_total=G['enc_b'][i], mode=0)
@@ -1113,8 +1131,9 @@ class VQVAE:
             if i == 0:
                 break
             if on_c:
-                K.f16x3_split_activations(dX, ws['eplanes'], B, F, Ti, scale_dev=es[5 + i:6 + i], mode=0)
-                K.f16x3_strided_conv(xp=ws['eplanes'], wp=ws['ewtp'][i - 1], out=ws['dX'][i - 1], B=B, T=Ti, Cin=F, M=F, ks=5,
+                if not w_planes:
+                    K.f16x3_split_activations(dX, ws['eplanes'], B, F, Ti, scale_dev=es[5 + i:6 + i], mode=0)
+                K.f16x3_strided_conv(xp=ws['edp'][i] if w_planes else ws['eplanes'], wp=ws['ewtp'][i - 1], out=ws['dX'][i - 1], B=B, T=Ti, Cin=F, M=F, ks=5,
                                      pad_left=pl, dgrad=True, x_scale=es[5 + i:6 + i], w_scale=es[0:1])
                 continue
             # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
