@@ -265,3 +265,73 @@ def test_relu_flip_detector():
     assert len(f) == 1 and not f[0]['benign'] and 'NOT within noise' in describe(f)
     with pytest.raises(ValueError):
         relu_flips({'t': (ref[:1], ref)})
+
+
+def test_generator_layout_policy(pkg, monkeypatch):
+    """generator.pick_layout: how a batch of utterances is cut into persistent handles (rows never interact, generate.py:40,103-113).
+    Up to 8 rows that fit the chip run as one-row handles with 8 channels per workgroup (R/8 workgroups each, ONE launch: measured
+    118 us per step for 8 utterances against 129 as two 4-row handles, profiles/round3_ar_layouts.txt); larger batches keep handles of
+    up to 4 rows; the environment overrides."""
+    g = pkg.generator
+    for k in ('VQW_AR_ROWS', 'VQW_AR_CPB'):
+        monkeypatch.delenv(k, raising=False)
+    assert g.pick_layout(1, 256, 256) == (1, 0)                      # one utterance: the library's choice (R/4 workgroups)
+    assert g.pick_layout(2, 256, 256) == (1, 8) and g.pick_layout(8, 256, 256) == (1, 8)      # 8 x 32 workgroups = 256 CUs
+    assert g.pick_layout(8, 256, 128) == (4, 0)                      # a chip with 128 CUs cannot hold 8 x 32 workgroups
+    assert g.pick_layout(9, 256, 256) == (3, 0) and g.pick_layout(20, 256, 256) == (4, 0)
+    assert g.pick_layout(6, 100, 256) == (3, 0)                      # R % 8 != 0: no 8-channel decomposition
+    monkeypatch.setenv('VQW_AR_ROWS', '2')
+    monkeypatch.setenv('VQW_AR_CPB', '4')
+    assert g.pick_layout(8, 256, 256) == (2, 4)
+
+
+def test_poisoned_allocations(pkg, monkeypatch):
+    """_alloc: with VQW_POISON every float buffer starts as NaN and the recorded ones are refilled by repoison(); integer buffers
+    (indices, labels: they are used as addresses) are left alone."""
+    A = pkg._alloc
+    monkeypatch.setattr(A, 'POISON', True)
+    rec = []
+    with A.record(rec):
+        a = A.empty(3, 4)
+        h = A.empty(8, dtype=torch.float16)
+        i = A.empty(5, dtype=torch.int64)
+    outside = A.empty(2)
+    assert len(rec) == 3 and torch.isnan(a).all() and torch.isnan(h).all() and torch.isnan(outside).all()
+    a.zero_(); h.zero_(); i.zero_()
+    A.repoison(rec)
+    assert torch.isnan(a).all() and torch.isnan(h).all() and int(i.abs().sum()) == 0
+    monkeypatch.setattr(A, 'POISON', False)
+    assert not torch.isnan(A.empty(4).fill_(1.0)).any()
+
+
+def test_grad_allreduce_force_runs_the_collectives_in_a_world_of_one(pkg, tmp_path):
+    """parallel.GradAllReduce(force=True): bucket slices, finish() and the flag's MAX all-reduce go through the process group even
+    with one rank (how a 1-GPU box exercises the data-parallel path on RCCL, tests/test_multirank_gpu.py); without `force` a world of
+    one short-circuits."""
+    import torch.distributed as dist
+    dist.init_process_group('gloo', init_method='file://%s' % (tmp_path / 'rdv'), rank=0, world_size=1)
+    try:
+        flat = torch.arange(10, dtype=torch.float32)
+        calls = []
+        real = dist.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append(t.numel())
+            return real(t, *a, **k)
+        dist.all_reduce = spy
+        try:
+            plain = pkg.parallel.GradAllReduce(flat)
+            plain.bucket_ready(0, 4)
+            assert plain.finish() == 1 and not plain.active and calls == []
+            forced = pkg.parallel.GradAllReduce(flat, force=True)
+            forced.bucket_ready(4, 10)
+            forced.bucket_ready(0, 4)
+            forced.bucket_ready(3, 3)                               # empty: ignored
+            assert forced.finish() == 1 and forced.last_buckets == [(4, 10), (0, 4)] and calls == [6, 4]
+            flag = torch.tensor([1], dtype=torch.int32)
+            assert int(forced.all_reduce_max(flag)) == 1 and calls == [6, 4, 1]
+        finally:
+            dist.all_reduce = real
+        assert torch.equal(flat, torch.arange(10, dtype=torch.float32))
+    finally:
+        dist.destroy_process_group()
