@@ -609,7 +609,7 @@ def test_wgrad_f16x3_stride2_matches_fp64(K, B, Tq, Tin, pl, scaled):
     assert (tot.double() - want_tot).abs().max().item() <= 1e-5 * q.abs().sum((0, 2)).max().item() + 2e-6 * tot0.abs().max().item()
     # the same gradient over the space-to-depth planes of p (what the forward conv reads) and the planes of q (what the input gradient
     # reads): tap j with e = j - pl is parity block e & 1 at row offset e >> 1 -- the same fp16 pieces, hence the same bits
-    if Tin == 2 * Tq and Tq % 32 == 0:
+    if Tin == 2 * Tq:          # (also where T_out is not a multiple of the 32-step pairs: 104 = encoder layer 5)
         pp = torch.empty(2 * B * Cp * Tin, dtype=torch.float16, device=DEV)
         qp = torch.empty(2 * B * Q0 * Tq, dtype=torch.float16, device=DEV)
         K.f16x3_split_activations(p, pp, B, Cp, Tin, scale_dev=sc[0:1], mode=K.X3_S2D)

@@ -45,7 +45,7 @@ def main():
         out, r, dx = torch.empty(B, F, Tout, device=DEV), torch.empty(B, F, Tout, device=DEV), torch.empty(B, F, Tin, device=DEV)
         gf = 2.0 * B * Tout * F * F * ks / 1e9
         row = ['T_out %4d (%.1f GFLOP):' % (Tout, gf)]
-        for shape in (1, 2, 3, 4):
+        for shape in (1, 2, 3, 4, 5):
             tf = timeit(lambda: K.f16x3_strided_conv(xp=xp, wp=wp, out=out, save_r=r, B=B, T=Tout, Cin=F, M=F, ks=ks, pad_left=pl, bias=bias,
                                                      bn_scale=bias, bn_shift=bias, relu=True, w_scale_inv=1 / 16.0, shape=shape))
             tb = timeit(lambda: K.f16x3_strided_conv(xp=dyp, wp=wtp, out=dx, B=B, T=Tout, Cin=F, M=F, ks=ks, pad_left=pl, dgrad=True,

@@ -254,6 +254,9 @@ struct OutArgs {
 #define VQW_WG_PAT_B 2      // ... and address computations / requests per MFMA in the second stage
 #endif
 
+#ifndef VQW_SCONV_64
+#define VQW_SCONV_64 1        // strided conv: 64-row blocks for launches that would leave three quarters of the chip idle
+#endif
 #ifndef VQW_SCONV_192
 #define VQW_SCONV_192 1       // strided conv: 192-row blocks where they fill more CUs than 256-row blocks (tools/sconv_bench.py)
 #endif
@@ -1082,7 +1085,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_f16x3_kernel(const WgArgs a) {
             // 128-byte line per chunk
             if (n < 4 * NPL) {
                 const int chunk = (n & 3) * 8 + (lane & 7), t = 8 * wv + (lane >> 3);
-                const int off = (int)(((size_t)chunk * NBq + (size_t)pb * T + pt0 + t) * 16);
+                // (T need not be a multiple of the 32-step pairs when both operands are planes: steps behind the row's end read as zero)
+                const int off = (pt0 + t < T) ? (int)(((size_t)chunk * NBq + (size_t)pb * T + pt0 + t) * 16) : (int)0x80000000;
                 rgq[n] = vqw_buf_load4((n >> 2) ? rqp1 : rqp0, off, 0);
             }
         } else {
@@ -1571,12 +1575,16 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     // 192-row blocks where they fill more CUs than 256-row blocks without a second round (768 rows x 52 column tiles: 208 blocks
     // instead of 156 on 256 CUs)
     if (d.shape == 0 && shape == 3 && d.M % 192 == 0 && (d.M / 192) * nt <= cus && VQW_SCONV_192) shape = 4;
-    VQW_CHECK(shape >= 1 && shape <= 4 && (shape != 3 || d.M % 256 == 0) && (shape != 4 || d.M % 192 == 0),
-              "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2, 3 (256-row blocks: M %% 256 == 0) or 4 (192-row blocks: M %% 192 == 0)");
+    // 64-row blocks for the shortest layers (encoder layers 4 and 5: 42 / 24 blocks of 128 rows on 256 CUs): twice the blocks at half
+    // the MFMAs per step -- 105 against 125 us per launch, tools/sconv_bench.py (a step then costs ~880 cycles for 384 of MFMA: the
+    // issue pattern has 12 MFMA shadows for ~20 memory instructions; four stages of requests in flight measured no better, 108 us)
+    if (d.shape == 0 && shape == 2 && (d.M / 128) * nt * 4 <= cus && VQW_SCONV_64) shape = 5;
+    VQW_CHECK(shape >= 1 && shape <= 5 && (shape != 3 || d.M % 256 == 0) && (shape != 4 || d.M % 192 == 0) && (shape != 5 || d.M % 64 == 0),
+              "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2, 3 (256-row blocks: M %% 256 == 0), 4 (192-row blocks: M %% 192 == 0) or 5 (64-row blocks)");
     typedef void (*kfn_t)(SconvArgs);
-    const kfn_t kfn = d.dgrad ? (shape == 4 ? sconv_f16x3_kernel<6, 2, true> : (shape == 3 ? sconv_f16x3_kernel<8, 2, true> : (shape == 2 ? sconv_f16x3_kernel<4, 2, true> : sconv_f16x3_kernel<4, 1, true>)))
-                              : (shape == 4 ? sconv_f16x3_kernel<6, 2, false> : (shape == 3 ? sconv_f16x3_kernel<8, 2, false> : (shape == 2 ? sconv_f16x3_kernel<4, 2, false> : sconv_f16x3_kernel<4, 1, false>)));
-    const int mr = shape == 4 ? 6 : (shape == 3 ? 8 : 4), lds = (shape == 1 ? 3 : 4) * (mr * 2 + 16) * 1024;      // DEPTH + 2 stages
+    const kfn_t kfn = d.dgrad ? (shape == 5 ? sconv_f16x3_kernel<2, 2, true> : (shape == 4 ? sconv_f16x3_kernel<6, 2, true> : (shape == 3 ? sconv_f16x3_kernel<8, 2, true> : (shape == 2 ? sconv_f16x3_kernel<4, 2, true> : sconv_f16x3_kernel<4, 1, true>))))
+                              : (shape == 5 ? sconv_f16x3_kernel<2, 2, false> : (shape == 4 ? sconv_f16x3_kernel<6, 2, false> : (shape == 3 ? sconv_f16x3_kernel<8, 2, false> : (shape == 2 ? sconv_f16x3_kernel<4, 2, false> : sconv_f16x3_kernel<4, 1, false>))));
+    const int mr = shape == 5 ? 2 : (shape == 4 ? 6 : (shape == 3 ? 8 : 4)), lds = (shape == 1 ? 3 : 4) * (mr * 2 + 16) * 1024;      // DEPTH + 2 stages
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_strided_conv: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL(kfn, dim3((d.M / (32 * mr)) * nt), dim3(256), lds, st, a);
@@ -1590,8 +1598,8 @@ int vqw_f16x3_wgrad_batch(const vqw_f16x3_wgrad_desc* dp, int nprob, vqw_stream_
     VQW_CHECK(nprob >= 1 && nprob <= WG_MAX_BATCH, "vqw_f16x3_wgrad_batch: 1..%d problems per launch (got %d)", WG_MAX_BATCH, nprob);
     const vqw_f16x3_wgrad_desc& d = dp[0];
     VQW_CHECK(d.slab, "vqw_f16x3_wgrad: null operand");
-    VQW_CHECK(d.B > 0 && d.T > 0 && (d.T % 32 == 0 || (d.p_stride == 2 && d.T % 4 == 0)),
-              "vqw_f16x3_wgrad: T must be a positive multiple of 32 (of 4 with p_stride 2) (got %d)", d.T);
+    VQW_CHECK(d.B > 0 && d.T > 0 && (d.T % 32 == 0 || (d.p_stride == 2 && d.T % 4 == 0) || (d.p_planes && d.q_planes && !d.q_seg)),
+              "vqw_f16x3_wgrad: T must be a positive multiple of 32 (of 4 with p_stride 2; any with both operands as planes) (got %d)", d.T);
     VQW_CHECK(d.Cp > 0 && d.Cp % 256 == 0 && d.Q0 > 0 && d.Q0 % 256 == 0 && d.Q1 >= 0 && d.Q1 % 256 == 0,
               "vqw_f16x3_wgrad: Cp, Q0, Q1 must be multiples of 256 (Cp=%d Q0=%d Q1=%d)", d.Cp, d.Q0, d.Q1);
     VQW_CHECK(d.ntaps >= 1 && d.ntaps <= VQW_MAX_TAPS, "vqw_f16x3_wgrad: 1..%d taps", VQW_MAX_TAPS);

@@ -1099,9 +1099,9 @@ class VQVAE:
             if side is not main:
                 ready = torch.cuda.Event()
                 ready.record(main)
-            # both operands as planes where the forward conv ran on the engine (its space-to-depth input planes were kept) and the
-            # K pairs are whole (T_out % 32): tap j, e = j - pad_left, is parity block e & 1 at row offset e >> 1
-            w_planes = on_w and on_c and 'esp' in ws and Ti % 32 == 0
+            # both operands as planes where the forward conv ran on the engine (its space-to-depth input planes were kept):
+            # tap j, e = j - pad_left, is parity block e & 1 at row offset e >> 1
+            w_planes = on_w and on_c and 'esp' in ws
             if w_planes:     # (the split the input gradient needs anyway, into this layer's own buffer, BEFORE the weight gradient)
                 K.f16x3_split_activations(dX, ws['edp'][i], B, F, Ti, scale_dev=es[5 + i:6 + i], mode=0)
                 if side is not main:
