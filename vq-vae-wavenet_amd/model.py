@@ -539,15 +539,17 @@ class VQVAE:
 
     def _decode_train(self, x, ws, save=True):
         """wavenet.py:24-100 -> ws['logits'] [B][Q][T], ws['labels']."""
+        self._decode_layers(ws, self._decode_prologue(x, ws, save))
+
+    def _decode_prologue(self, x, ws, save=True):
+        """Everything of the decoder's forward pass that does not depend on the encoder: inputs / labels, the preprocess conv
+        (wavenet.py:33-44), this step's guard scales and weight planes, the skip start (wavenet.py:53-54).  Returns the
+        plan of the step (which engine carries what, the guard slots) for _decode_layers."""
         P, R, S, Q, L, B, T, Tz = self.P, self.R, self.S, self.Q, self.L, ws['B'], ws['T'], ws['Tz']
         K.wavenet_inputs(x, ws['inputs'], ws['labels'])                                   # wavenet.py:33-37
-        K.conv_gemm(x0=ws['cond'], w=P['cond_w'], out0=ws['condenc'], B=B, T_in=Tz, T_out=Tz, M=self.Mall,
-                    C0=self.Cc, taps=[0])                                                 # all add_condition 1x1s
         net = ws['net']
         K.conv_cin1_fwd(ws['inputs'], P['pre_w'], P['pre_b'], net[0], k=self.pre_k, stride=1,
                         offset=-(self.pre_k - 1))                                         # wavenet.py:42-44
-        cbs = self.Mall * Tz
-        ce_flat = ws['condenc'].view(-1)   # layer l's rows start at l*2R*Tz inside every batch block
         # fp16x3 needs whole 256-step tiles inside a batch row, 128-channel blocks and one condition frame per 32 steps;
         # |w| < 255 and |net| < 65504 (fp16 range of the leading planes) are assumed, not checked
         f16x3 = self.gate_f16x3 and T % 256 == 0 and R % 128 == 0 and (T // Tz) % 32 == 0
@@ -617,6 +619,20 @@ class VQVAE:
                 K.f16x3_pack_weights(P['out_w'].view(-1)[S:], ws['wres'], R, R, S + R, WS, count=L, scale_dev=sc('WO'), mode=md)
             elif f16x3_out:
                 K.f16x3_pack_weights(P['out_w'], ws['wop_all'], R, S + R, S + R, WS, count=L, mode=md)
+        return dict(f16x3=f16x3, f16x3_skip=f16x3_skip, f16x3_out=f16x3_out, ngrp=ngrp, Lg=Lg, md=md, gd=gd, sc=sc, am=am, flag=flag, WS=WS,
+                    head_x3=head_x3, xpl=xpl, drop_th=drop_th, drop_g=drop_g, save=save)
+
+    def _decode_layers(self, ws, plan):
+        """The condition projections, the residual stack and the convs behind it (wavenet.py:58-100; wavenet_ops.py:93-138)."""
+        P, R, S, Q, L, B, T, Tz = self.P, self.R, self.S, self.Q, self.L, ws['B'], ws['T'], ws['Tz']
+        f16x3, f16x3_skip, f16x3_out, ngrp, Lg, md, gd = (plan[k] for k in ('f16x3', 'f16x3_skip', 'f16x3_out', 'ngrp', 'Lg', 'md', 'gd'))
+        sc, am, flag, WS, head_x3, xpl, drop_th, drop_g, save = (plan[k] for k in ('sc', 'am', 'flag', 'WS', 'head_x3', 'xpl', 'drop_th',
+                                                                                  'drop_g', 'save'))
+        net = ws['net']
+        K.conv_gemm(x0=ws['cond'], w=P['cond_w'], out0=ws['condenc'], B=B, T_in=Tz, T_out=Tz, M=self.Mall,
+                    C0=self.Cc, taps=[0])                                                 # all add_condition 1x1s
+        cbs = self.Mall * Tz
+        ce_flat = ws['condenc'].view(-1)   # layer l's rows start at l*2R*Tz inside every batch block
         for l, d in enumerate(self.dil):
             if f16x3:
                 if (l == 0 and not head_x3) or not f16x3_out:
@@ -683,8 +699,11 @@ class VQVAE:
         ws = self._workspace(B, T)
         if A.POISON:             # debug: every workspace buffer and the transposed-kernel scratch start the step as NaN
             A.repoison(ws['_poison'] + self._poison_T)
+        # (the decoder's encoder-independent prologue on the side stream under the encoder's short layers measured null, 27.0 vs
+        # 27.0 ms: the step is not bound by those ~35 small launches)
+        plan = self._decode_prologue(x, ws)
         self._encode(x, spk, ws)
-        self._decode_train(x, ws)
+        self._decode_layers(ws, plan)
         self.loss_buf.zero_()
         N = B * T
         K.softmax_xent(ws['logits'], ws['labels'], loss_sum=self.loss_buf[0:1],
