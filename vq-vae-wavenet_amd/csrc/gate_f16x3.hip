@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void out_f16x3_kernel(const O
 //   out[b][m][t] = mask * (net_in[b][m][t] + (W x)[m] + bias[m] + cond[b][m][t / ratio]),   mask = (aux0[b][m][t] > 0) or 1
 // (net_in, bias, cond, aux0 optional; out may be net_in and / or aux0: every element is read and written by one lane), and
 // out -- or relu(out), flags bit 0 -- once more as planes for the next contraction, range-checked like the others.
-template <int MR>
+template <int MR, bool BF = false>
 __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void head_f16x3_kernel(const OutArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const vqw_f16x3_out_desc& d = a.d;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void head_f16x3_kernel(const 
         g.wp = d.wp; g.xp = d.xp; g.M = M; g.Cin = d.Cin; g.ks = 1; g.dilation = 1; g.NB = a.NB;
         g.xKC = d.xp_KC > 0 ? d.xp_KC : d.Cin / 8; g.xkc0 = d.xp_kc0; g.dir = 1; g.T = T;
         g.m_row0 = mt * HB; g.n0 = n0; g.t0 = t0;
-        f16x3_mainloop<false, MR>(acc, smem, g, wv, lane);
+        f16x3_mainloop<BF, MR>(acc, smem, g, wv, lane);
     }
     const bool hb = d.bias != nullptr, hc = d.cond != nullptr, hin = d.net_in != nullptr, hm = d.aux0 != nullptr;
     const bool relu_planes = (d.flags & 1) != 0;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void head_f16x3_kernel(const 
                         if (relu_planes) nq[j][e] = fmaxf(nq[j][e], 0.0f);
                         gmax = fmaxf(gmax, fabsf(nq[j][e]));
                     }
-                    store_plane_quad<false>(d.net_out_planes, PKC, a.NB, d.planes_kc0 + m0 / 8, n0 + 64 * wv + 32 * j + l31, lhi, nq[j], ps);
+                    store_plane_quad<BF>(d.net_out_planes, PKC, a.NB, d.planes_kc0 + m0 / 8, n0 + 64 * wv + 32 * j + l31, lhi, nq[j], ps);
                 }
             }
         }
@@ -1486,10 +1486,10 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     const int lds = half ? X3Shape<4>::LDS_BYTES : X3Shape<8>::LDS_BYTES, hb = half ? 128 : 256;
     const bool bwd = d.epi == 1;
     if (d.epi == 2) {
-        VQW_CHECK(d.S == 0 && d.R > 0 && d.net_out && d.Cin > 0 && !bf && d.ks <= 1, "vqw_f16x3_out_conv: epi 2 needs S = 0, net_out, Cin, a 1x1 kernel and the fp16x3 mode");
+        VQW_CHECK(d.S == 0 && d.R > 0 && d.net_out && d.Cin > 0 && d.ks <= 1, "vqw_f16x3_out_conv: epi 2 needs S = 0, net_out, Cin and a 1x1 kernel");
         VQW_CHECK(!d.cond || (d.cond_T > 0 && d.T % d.cond_T == 0 && (d.T / d.cond_T) % 32 == 0 && d.cond_bstride >= (int64_t)d.R * d.cond_T),
                   "vqw_f16x3_out_conv: T / cond_T must be a multiple of 32 (T=%d cond_T=%d)", d.T, d.cond_T);
-        const kfn_t kfn = half ? head_f16x3_kernel<4> : head_f16x3_kernel<8>;
+        const kfn_t kfn = bf ? (half ? head_f16x3_kernel<4, true> : head_f16x3_kernel<8, true>) : (half ? head_f16x3_kernel<4> : head_f16x3_kernel<8>);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", lds);
         hipLaunchKernelGGL(kfn, dim3((d.R / hb) * (a.NB / 256)), dim3(256), lds, st, a);
@@ -1500,11 +1500,12 @@ int vqw_f16x3_out_conv(const vqw_f16x3_out_desc* dp, vqw_stream_t s_) {
     kfn_t kfn = (bwd ? kbwds : kouts)[(bf ? 1 : 0) + (half ? 2 : 0)];
     if (bwd && (d.flags & 6)) {
         const bool pl = (d.flags & 4) != 0;      // bit 2: aux0 = the gated planes [planes][aux0_KC][B*T][8] from chunk aux0_kc0
-        VQW_CHECK(!bf || pl, "vqw_f16x3_out_conv: gate backward from the fp32 gated output (flags bit 1) exists in the fp16x3 mode only");
+
         VQW_CHECK(!pl || (d.aux0_kc0 >= 0 && d.aux0_kc0 + d.R / 8 <= (d.aux0_KC > 0 ? d.aux0_KC : d.R / 8)), "vqw_f16x3_out_conv: bad chunk range of the gated planes");
-        const kfn_t kg[6] = {gate_bwd_f16x3_kernel<false, 8, 1>, gate_bwd_f16x3_kernel<false, 4, 1>, gate_bwd_f16x3_kernel<false, 8, 2>,
-                             gate_bwd_f16x3_kernel<false, 4, 2>, gate_bwd_f16x3_kernel<true, 8, 2>, gate_bwd_f16x3_kernel<true, 4, 2>};
-        kfn = kg[(pl ? (bf ? 4 : 2) : 0) + (half ? 1 : 0)];
+        const kfn_t kg[8] = {gate_bwd_f16x3_kernel<false, 8, 1>, gate_bwd_f16x3_kernel<false, 4, 1>, gate_bwd_f16x3_kernel<false, 8, 2>,
+                             gate_bwd_f16x3_kernel<false, 4, 2>, gate_bwd_f16x3_kernel<true, 8, 2>, gate_bwd_f16x3_kernel<true, 4, 2>,
+                             gate_bwd_f16x3_kernel<true, 8, 1>, gate_bwd_f16x3_kernel<true, 4, 1>};
+        kfn = kg[(pl ? (bf ? 4 : 2) : (bf ? 6 : 0)) + (half ? 1 : 0)];
     }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return vqw_set_error("vqw_f16x3_out_conv: cannot reserve %d bytes of LDS", lds);

@@ -409,7 +409,7 @@ class VQVAE:
             if self.skip_f16x3:
                 ws['wskip'] = A.empty(2 * L * R * S, dtype=torch.float16, device=dev)
                 ws['wres'] = A.empty(L, 2 * R * R, dtype=torch.float16, device=dev)
-                if self.x3_guard and self.gbwd_f16x3 and S % 256 == 0 and Q % 256 == 0:     # the convs around the stack on the engine too
+                if (self.x3_guard or self.bf16) and self.gbwd_f16x3 and S % 256 == 0 and Q % 256 == 0:     # the convs around the stack on the engine too
                     ws['hp'] = A.empty(2 * B * S * T, dtype=torch.float16, device=dev)     # relu(skip) / d postprocess1 planes
                     ws['hp2'] = A.empty(2 * B * S * T, dtype=torch.float16, device=dev)    # relu(postprocess1) / d logits planes
                     for name, n_ in (('wskip0', R * S), ('wpost1', S * S), ('wpost2', S * Q)):
@@ -578,7 +578,7 @@ class VQVAE:
         am = (lambda name, i=0: self.x3_amax[self.SL[name] + i:self.SL[name] + i + 1]) if gd else (lambda name, i=0: None)
         flag = self.x3_flag if gd else None
         WS = 1.0 if gd else 256.0          # guarded: the weight scale lives on the device (exact max-abs of this step's weights)
-        head_x3 = ws['head_x3'] = bool(gd and self.head_x3 and 'hp' in ws and T % 32 == 0)
+        head_x3 = ws['head_x3'] = bool((gd or (self.bf16 and f16x3_skip)) and self.head_x3 and 'hp' in ws and T % 32 == 0)
         # layer l's input planes: kept per layer for the weight gradients where the skip contraction runs on the engine (then
         # every layer hands its successor planes), else one buffer (slot L: the planes of net[L], which nothing reads)
         keep_xp = bool('xp_all' in ws and f16x3_skip)
@@ -586,10 +586,10 @@ class VQVAE:
         xpl = (lambda l: ws['xp_all'][l]) if keep_xp else (lambda l: ws['xp'])    # noqa: E731
         # the guarded engine's gate backward forms tanh = gated / sigmoid itself: tanh is not stored (54 MB less per layer and gate
         # conv, 166 -> 157 us); VQW_SAVE_TANH=1 stores it
-        drop_th = ws['th_dropped'] = bool(gd and self.gbwd_f16x3 and os.environ.get('VQW_SAVE_TANH', '0') != '1')
+        drop_th = ws['th_dropped'] = bool((gd or (self.bf16 and f16x3_skip)) and self.gbwd_f16x3 and os.environ.get('VQW_SAVE_TANH', '0') != '1')
         # ... and then nothing reads the fp32 gated output either (gate backward and the 1x1 kernels' weight gradients take the
         # gated planes): the gate conv does not write it (54 MB less per layer)
-        drop_g = ws['gated_dropped'] = bool(keep_xp and save and drop_th and os.environ.get('VQW_WGRAD_BATCH', '1') != '0'
+        drop_g = ws['gated_dropped'] = bool(gd and keep_xp and save and drop_th and os.environ.get('VQW_WGRAD_BATCH', '1') != '0'
                                             and os.environ.get('VQW_SAVE_GATED', '0') != '1')
         if gd:
             K.f16x3_amax(P['gated_w'], am('WG'), flag=flag)
@@ -598,10 +598,11 @@ class VQVAE:
             # weights and the first layer's input: exact scales (amax < 2^14 after scaling); the collectors restart
             K.f16x3_update_scales(self.x3_amax[:2], self.x3_scale[:2], target_exp=14, flag=flag)
             K.f16x3_update_scales(am('X', 0), sc('X', 0), target_exp=13, flag=flag)
-        if head_x3:      # the three kernels around the stack share one scale
-            for name in ('skip0_w', 'post1_w', 'post2_w'):
-                K.f16x3_amax(P[name], am('WH'), flag=flag)
-            K.f16x3_update_scales(am('WH'), sc('WH'), target_exp=14, flag=flag)
+        if head_x3:      # the three kernels around the stack share one scale (bf16 planes need none)
+            if gd:
+                for name in ('skip0_w', 'post1_w', 'post2_w'):
+                    K.f16x3_amax(P[name], am('WH'), flag=flag)
+                K.f16x3_update_scales(am('WH'), sc('WH'), target_exp=14, flag=flag)
             K.f16x3_pack_weights(P['skip0_w'], ws['wskip0'], R, S, S, 1.0, scale_dev=sc('WH'), mode=md)
             K.f16x3_pack_weights(P['post1_w'], ws['wpost1'], S, S, S, 1.0, scale_dev=sc('WH'), mode=md)
             K.f16x3_pack_weights(P['post2_w'], ws['wpost2'], S, Q, Q, 1.0, scale_dev=sc('WH'), mode=md)
@@ -798,14 +799,15 @@ class VQVAE:
         dlog, h1, skip = ws['logits'], ws['h1'], ws['skip']
         cbs = self.Mall * Tz
         dce = ws['dcondenc']
-        head_x3 = bool(ws.get('head_x3')) and bool(ws.get('x3_used')) and self.x3_guard
+        head_x3 = bool(ws.get('head_x3')) and bool(ws.get('x3_used')) and (self.x3_guard or self.bf16)
+        GSh = 1.0 if self.x3_guard else float(2 ** 20)      # the gradient planes' lift where no device scale carries it (bf16 engine)
         if head_x3:
             # the convs around the stack on the fp16x3 engine (forward: _decode_train): d logits as planes with a fixed scale
             # (|d logits| <= 1 / (B T)), each input gradient hands the next one its planes, the weight gradients split their fp32
             # operands in registers (p = relu of the forward tensor), bias and condition sums ride along
-            hsc = lambda name: self.x3_scale[self.SL[name]:self.SL[name] + 1]      # noqa: E731
-            ham = lambda name: self.x3_amax[self.SL[name]:self.SL[name] + 1]       # noqa: E731
-            mdh, dl, hflag = self.x3_mode_bwd, ws['dl_scale'], self.x3_flag
+            hsc = (lambda name: self.x3_scale[self.SL[name]:self.SL[name] + 1]) if self.x3_guard else (lambda name: None)      # noqa: E731
+            ham = (lambda name: self.x3_amax[self.SL[name]:self.SL[name] + 1]) if self.x3_guard else (lambda name: None)       # noqa: E731
+            mdh, dl, hflag = self.x3_mode_bwd, ws['dl_scale'], (self.x3_flag if self.x3_guard else None)
             self._wslab(ws)
             K.f16x3_pack_weights(Tt['post2_w'], ws['wpost2t'], Q, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
             K.f16x3_pack_weights(Tt['post1_w'], ws['wpost1t'], S, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
@@ -823,7 +825,7 @@ class VQVAE:
                           p_scale=hsc('SK'), q0_scale=hsc('DH'), q_total=G['post1_b'], q_seg=dce.view(-1)[L * 2 * R * Tz:], seg_T=Tz,
                           seg_bstride=cbs, mode=mdh)
             K.f16x3_out_conv(epi=2, xp=ws['hp'], Cin=S, wp=ws['wpost1t'], net_out=skip, aux0=skip, net_out_planes=ws['gr'],
-                             planes_kc0=0, planes_KC=(S + R) // 8, B=B, T=T, R=S, S=0, w_scale_inv=1.0, x_scale=hsc('DH'),
+                             planes_kc0=0, planes_KC=(S + R) // 8, plane_scale=GSh, B=B, T=T, R=S, S=0, w_scale_inv=1.0, x_scale=hsc('DH'),
                              w_scale=hsc('WH'), out_scale=hsc('G'), out_amax=ham('G'), flag=hflag, mode=mdh)   # skip := d skip, and its planes
         else:
             # ---- postprocess2 (wavenet.py:93-96)
@@ -1045,7 +1047,7 @@ class VQVAE:
         # ---- skip start + preprocess (wavenet.py:42-55)
         if head_x3 and gbwd_x3:      # dnet += W_skip0^T dskip over dskip's planes (chunks 0..S/8 of the gradient planes)
             K.f16x3_out_conv(xp=ws['gr'], xp_KC=(S + R) // 8, Cin=S, wp=ws['wskip0t'], net_in=dnet, net_out=dnet, B=B, T=T, R=R, S=0,
-                             w_scale_inv=1.0, x_scale=sc('G'), w_scale=sc('WH'), mode=md)
+                             w_scale_inv=1.0 / GS, x_scale=sc('G'), w_scale=sc('WH'), mode=md)
         else:
             K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
                         C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
