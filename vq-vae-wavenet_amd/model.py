@@ -918,8 +918,8 @@ class VQVAE:
             else:
                 ws['dpre_all'] = [A.empty(B, 2 * R, T, device=self.dev) for _ in range(L)]
             ws['_poison'] += ws['dp_all' if qp else 'dpre_all']
-        gate_batch = int(os.environ.get('VQW_WG_GATE_BATCH', '6'))      # 36 tiles x 7 K splits = 252 blocks (tools/wg_batch_sweep.sh)
-        res_batch = int(os.environ.get('VQW_WG_RES_BATCH', '29'))
+        gate_batch = max(1, min(K.WGRAD_MAX_BATCH, int(os.environ.get('VQW_WG_GATE_BATCH', '6'))))      # 36 tiles x 7 K splits = 252 blocks (tools/wg_batch_sweep.sh)
+        res_batch = max(1, min(K.WGRAD_MAX_BATCH, int(os.environ.get('VQW_WG_RES_BATCH', '29'))))
         pend_gate, pend_res = {False: [], True: []}, []
 
         def on_side(launch):           # weight gradients: nothing downstream waits for them
