@@ -424,7 +424,27 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
     const int lab = ok ? labels[(size_t)b * T + t] : 0;
     float m = -INFINITY, s = 0.0f, xl = 0.0f;
     if (ok) {
-        for (int q = 0; q < qn; ++q) {
+        // chunks of 16 channels: sixteen independent loads in flight, one running-max update per chunk (element by element the
+        // online softmax is a dependent chain of exps behind one load each: 59 us for 109 MB = 23 % of the HBM peak in round 2)
+        int q = 0;
+        for (; q + 16 <= qn; q += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = lp[(size_t)(q + u) * T];
+            float cm = v[0];
+#pragma unroll
+            for (int u = 1; u < 16; ++u) cm = fmaxf(cm, v[u]);
+            const float mn = fmaxf(m, cm);
+            float cs = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                cs += __expf(v[u] - mn);
+                if (q0 + q + u == lab) xl = v[u];
+            }
+            s = s * __expf(m - mn) + cs;
+            m = mn;
+        }
+        for (; q < qn; ++q) {
             const float v = lp[(size_t)q * T];
             if (q0 + q == lab) xl = v;
             const float mn = fmaxf(m, v);
@@ -448,7 +468,19 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
     if (ok && (dlogits || probs)) {
         const float inv = 1.0f / S;
         const size_t base = ((size_t)b * Q + q0) * T + t;
-        for (int q = 0; q < qn; ++q) {
+        int q = 0;
+        for (; q + 16 <= qn; q += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = lp[(size_t)(q + u) * T];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float p = __expf(v[u] - M) * inv;
+                if (probs) probs[base + (size_t)(q + u) * T] = p;
+                if (dlogits) dlogits[base + (size_t)(q + u) * T] = (p - ((q0 + q + u == lab) ? 1.0f : 0.0f)) * grad_scale;
+            }
+        }
+        for (; q < qn; ++q) {
             const float p = __expf(lp[(size_t)q * T] - M) * inv;
             if (probs) probs[base + (size_t)q * T] = p;
             if (dlogits) dlogits[base + (size_t)q * T] = (p - ((q0 + q == lab) ? 1.0f : 0.0f)) * grad_scale;
