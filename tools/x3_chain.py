@@ -29,31 +29,33 @@ class Chain:
         self.gr = torch.empty(2 * B * (S + R) * T, dtype=torch.float16, device=dev)
         self.dpre, self.dnet = torch.empty(B, 2 * R, T, device=dev), [rnd(B, R, T, sc=1e-5) for _ in range(2)]
         K.f16x3_split_activations(self.net[0], self.xp, B, R, T)
+        K.f16x3_split_activations(self.th * self.sg, self.gp, B, R, T)
         K.f16x3_split_activations(rnd(B, S, T, sc=1e-5), self.gr, B, S, T, scale=2.0 ** 20, kc0=0, KC=(S + R) // 8)
         K.f16x3_split_activations(self.dnet[0], self.gr, B, R, T, scale=2.0 ** 20, kc0=S // 8, KC=(S + R) // 8)
 
-    def forward(self, W):
+    def forward(self, W):      # as model.py runs it since round 3: no fp32 gated output, tanh not stored, 128-row blocks
         B = self.B
         for l in range(L):
-            K.f16x3_gate_conv(xp=self.xp, wp=W['wp'], out0=self.gated, save0=self.th, save1=self.sg, B=B, T=T, R=R, ks=ks,
-                              dilation=dil[l], w_scale_inv=1 / 256.0, out_planes=self.gp)
+            K.f16x3_gate_conv(xp=self.xp, wp=W['wp'], out0=None, save1=self.sg, B=B, T=T, R=R, ks=ks,
+                              dilation=dil[l], w_scale_inv=1 / 256.0, out_planes=self.gp, mode=HB)
             K.f16x3_out_conv(xp=self.gp, wp=W['wres'], net_in=self.net[l % 2], net_out=self.net[(l + 1) % 2], net_out_planes=self.xp,
-                             B=B, T=T, R=R, S=0, w_scale_inv=1 / 256.0)
+                             B=B, T=T, R=R, S=0, w_scale_inv=1 / 256.0, mode=HB)
 
-    def backward(self, W):
+    def backward(self, W):     # gate backward from the gated planes, dpre as planes only (128-row blocks); input gradient 256-row blocks
         B = self.B
         for l in range(L):
-            K.f16x3_out_conv(epi=1, xp=self.gr, Cin=S + R, xp_KC=(S + R) // 8, wp=W['wgb'], aux0=self.th, aux1=self.sg, net_out=self.dpre,
-                             net_out_planes=self.dp, plane_scale=2.0 ** 20, B=B, T=T, R=R, S=0, w_scale_inv=2.0 ** -28)
+            K.f16x3_out_conv(epi=1, xp=self.gr, Cin=S + R, xp_KC=(S + R) // 8, wp=W['wgb'], aux0_planes=self.gp, aux0_is_gated=True, aux1=self.sg,
+                             net_out=None, net_out_planes=self.dp, plane_scale=2.0 ** 20, B=B, T=T, R=R, S=0, w_scale_inv=2.0 ** -28, mode=HB)
             K.f16x3_out_conv(xp=self.dp, Cin=2 * R, ks=ks, dilation=dil[l], direction=-1, wp=W['wdg'], net_in=self.dnet[l % 2],
                              net_out=self.dnet[(l + 1) % 2], B=B, T=T, R=R, S=0, w_scale_inv=2.0 ** -28, net_out_planes=self.gr,
-                             planes_kc0=S // 8, planes_KC=(S + R) // 8, plane_scale=2.0 ** 20)
+                             planes_kc0=S // 8, planes_KC=(S + R) // 8, plane_scale=2.0 ** 20, mode=0)
 
 
+HB = K.X3_HALF_BLOCKS
 gw, ow = rnd(ks, R, 2 * R, sc=0.06), rnd(R, S + R, sc=0.06)
 W = {'wp': torch.empty(2 * ks * R * 2 * R, dtype=torch.float16, device=dev), 'wres': torch.empty(2 * R * R, dtype=torch.float16, device=dev),
      'wdg': torch.empty(2 * ks * 2 * R * R, dtype=torch.float16, device=dev), 'wgb': torch.empty(2 * (S + R) * R, dtype=torch.float16, device=dev)}
-K.f16x3_pack_gate_weights(gw, W['wp'], ks, R, 2 * R, 256.0)
+K.f16x3_pack_gate_weights(gw, W['wp'], ks, R, 2 * R, 256.0, mode=HB)
 K.f16x3_pack_weights(ow.view(-1)[S:], W['wres'], R, R, S + R, 256.0)
 K.f16x3_pack_weights(gw.permute(0, 2, 1).contiguous(), W['wdg'], ks * 2 * R, R, R, 256.0)
 K.f16x3_pack_weights(ow.t().contiguous(), W['wgb'], S + R, R, R, 256.0)
