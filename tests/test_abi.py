@@ -32,14 +32,20 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_ctypes_structs_match_c_layout(pkg, tmp_path):
     L = pkg._lib
     prog = tmp_path / 'sz.c'
-    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vqwave.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vqwave.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(vqw_conv_desc), offsetof(vqw_conv_desc, x0), sizeof(vqw_wgrad_desc), offsetof(vqw_wgrad_desc, p),'
-                    'sizeof(vqw_ar_weights), offsetof(vqw_ar_weights, post2_w));return 0;}\n')
+                    'sizeof(vqw_ar_weights), offsetof(vqw_ar_weights, post2_w),'
+                    'sizeof(vqw_f16x3_gate_desc), sizeof(vqw_f16x3_out_desc), offsetof(vqw_f16x3_out_desc, aux0_kc0),'
+                    'sizeof(vqw_f16x3_sconv_desc), sizeof(vqw_f16x3_wgrad_desc), offsetof(vqw_f16x3_wgrad_desc, q_planes),'
+                    'offsetof(vqw_f16x3_wgrad_desc, p_tap_chunk));return 0;}\n')
     exe = tmp_path / 'sz'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(prog), '-o', str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(L.ConvDesc), L.ConvDesc.x0.offset, ctypes.sizeof(L.WgradDesc), L.WgradDesc.p.offset,
-            ctypes.sizeof(L.ArWeights), L.ArWeights.post2_w.offset]
+            ctypes.sizeof(L.ArWeights), L.ArWeights.post2_w.offset,
+            ctypes.sizeof(L.F16x3GateDesc), ctypes.sizeof(L.F16x3OutDesc), L.F16x3OutDesc.aux0_kc0.offset,
+            ctypes.sizeof(L.F16x3SconvDesc), ctypes.sizeof(L.F16x3WgradDesc), L.F16x3WgradDesc.q_planes.offset,
+            L.F16x3WgradDesc.p_tap_chunk.offset]
     assert got == want
 
 
