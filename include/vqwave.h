@@ -458,7 +458,20 @@ typedef struct vqw_f16x3_sconv_desc {
     float w_scale_inv;
     int32_t B, T, Cin, M, ks, pad_left, relu, dgrad;
     int32_t shape;          /* 0 = by how the launch fills the chip; 1: 128-row blocks, two per CU; 2: 128-row blocks, one per
-                             * CU with deeper prefetch; 3: 256-row blocks (M % 256 == 0); 4: 192-row blocks (M % 192 == 0)    */
+                             * CU with deeper prefetch; 3: 256-row blocks (M % 256 == 0); 4: 192-row blocks (M % 192 == 0);
+                             * 5: 64-row blocks                                                                               */
+    /* Split-K for launches that would leave most of the chip idle (encoder layers 2-5: 24..156 tiles of 240 K steps on 256 CUs):
+     * with scratch given, the K steps of a tile are cut over `ksplit` blocks (and the two output parities of an input gradient go
+     * to separate blocks); the partial tiles meet in split_slab and the last block to arrive at a tile adds them in a fixed order
+     * and runs the epilogue (results are bitwise reproducible).  ksplit: 0 = chosen by the launch's tile count, 1 = off, n = n
+     * blocks per tile (the K steps of every parity must divide into n even parts).  split_slab: blocks * rows per block * 256
+     * floats (CUs * 65536 always suffices); split_counters: one int per tile, ZERO before the first launch (left zero by every
+     * launch).                                                                                                              */
+    float* split_slab;
+    int64_t split_slab_floats;
+    int32_t* split_counters;
+    int32_t split_counters_n;
+    int32_t ksplit;
 } vqw_f16x3_sconv_desc;
 int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* d, vqw_stream_t s);
 

@@ -678,6 +678,79 @@ def test_strided_conv_f16x3_forward_and_input_gradient(K, B, Tout, Cin, M):
     assert (dx.double() - want_dx.double()).abs().max().item() <= tol * want_dx.abs().max().item()
 
 
+@pytest.mark.parametrize('B,Tout,Cin,M,shape,ksplit', [(3, 104, 256, 256, 2, 4), (2, 128, 256, 256, 0, 2), (1, 96, 256, 128, 2, 2),
+                                                       (8, 104, 768, 768, 0, 0), (8, 208, 768, 768, 0, 0)])
+def test_strided_conv_f16x3_split_k(K, B, Tout, Cin, M, shape, ksplit):
+    """Split-K launches of vqw_f16x3_strided_conv (the short encoder layers: few tiles of many K steps): the K steps of a tile over
+    several blocks, the output parities of the input gradient over separate blocks, partial tiles summed by the last block to arrive
+    in a fixed order -- against fp64 (the fp32 engine at the benchmark's layers 4 and 5), bitwise equal from launch to launch, the
+    ticket counters back at zero."""
+    import torch.nn.functional as Fn
+    ks, pl, Tin = 5, 1, 2 * Tout
+    gen = torch.Generator().manual_seed(77 + Tout + ksplit)
+    x = torch.randn(B, Cin, Tin, generator=gen).to(DEV)
+    w = (torch.randn(ks, Cin, M, generator=gen) * 0.05).to(DEV)
+    bias, bsc, bsh = (torch.randn(M, generator=gen).to(DEV) * s_ for s_ in (0.5, 1.0, 0.3))
+    sc = torch.tensor([8.0, 256.0, 2.0 ** 22], device=DEV)
+    xp = torch.empty(2 * B * Cin * Tin, dtype=torch.float16, device=DEV)
+    wp = torch.empty(2 * ks * Cin * M, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(x, xp, B, Cin, Tin, scale_dev=sc[0:1], mode=K.X3_S2D)
+    K.f16x3_pack_weights(w, wp, ks * Cin, M, M, 1.0, scale_dev=sc[1:2], mode=0)
+    slab = torch.full((torch.cuda.get_device_properties(0).multi_processor_count * 65536,), float('nan'), device=DEV)
+    cnt = torch.zeros(1024, dtype=torch.int32, device=DEV)
+    outs = []
+    for rep in range(2):
+        out, r = torch.full((B, M, Tout), float('nan'), device=DEV), torch.full((B, M, Tout), float('nan'), device=DEV)
+        K.f16x3_strided_conv(xp=xp, wp=wp, out=out, save_r=r, B=B, T=Tout, Cin=Cin, M=M, ks=ks, pad_left=pl, bias=bias, bn_scale=bsc,
+                             bn_shift=bsh, relu=True, x_scale=sc[0:1], w_scale=sc[1:2], shape=shape, split_slab=slab, split_counters=cnt,
+                             ksplit=ksplit)
+        outs.append((out, r))
+        assert int(cnt.abs().sum().item()) == 0, 'ticket counters not back at zero'
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), 'split-K forward differs from launch to launch'
+    out, r = outs[0]
+    big = Cin >= 768
+    if big:
+        want, want_r = torch.empty_like(out), torch.empty_like(r)
+        K.conv_gemm(x0=x, w=w, bias=bias, out0=want, save0=want_r, scale=bsc, shift=bsh, B=B, T_in=Tin, T_out=Tout, M=M, C0=Cin,
+                    in_stride=2, taps=[j - pl for j in range(ks)], out_relu=True)
+    else:
+        y = Fn.conv1d(Fn.pad(x.double(), (pl, ks - 2 - pl)), w.permute(2, 1, 0).double(), bias.double(), stride=2)
+        want_r = torch.relu(y)
+        want = bsc.double()[None, :, None] * want_r + bsh.double()[None, :, None]
+    tol = 2e-5 if big else 3e-6
+    assert torch.isfinite(out).all() and torch.isfinite(r).all()
+    assert (r.double() - want_r.double()).abs().max().item() <= tol * want_r.abs().max().item()
+    assert (out.double() - want.double()).abs().max().item() <= tol * want.abs().max().item()
+    dy = (torch.randn(B, M, Tout, generator=gen) * 1e-4).to(DEV)
+    wt = w.permute(0, 2, 1).contiguous()
+    dyp = torch.empty(2 * B * M * Tout, dtype=torch.float16, device=DEV)
+    wtp = torch.empty(2 * ks * M * Cin, dtype=torch.float16, device=DEV)
+    K.f16x3_split_activations(dy, dyp, B, M, Tout, scale_dev=sc[2:3], mode=0)
+    K.f16x3_pack_weights(wt, wtp, ks * M, Cin, Cin, 1.0, scale_dev=sc[1:2], mode=0)
+    dxs = []
+    for rep in range(2):
+        dx = torch.full((B, Cin, Tin), float('nan'), device=DEV)
+        K.f16x3_strided_conv(xp=dyp, wp=wtp, out=dx, B=B, T=Tout, Cin=M, M=Cin, ks=ks, pad_left=pl, dgrad=True, x_scale=sc[2:3],
+                             w_scale=sc[1:2], shape=shape, split_slab=slab, split_counters=cnt, ksplit=ksplit)
+        dxs.append(dx)
+        assert int(cnt.abs().sum().item()) == 0
+    assert torch.equal(dxs[0], dxs[1]), 'split-K input gradient differs from launch to launch'
+    dx = dxs[0]
+    if big:
+        want_dx = torch.empty_like(dx)
+        for p in (0, 1):
+            j0 = (p + pl) % 2
+            js = list(range(j0, ks, 2))
+            K.conv_gemm(x0=dy, w=wt[j0:], w_tap_stride=2 * M * Cin, out0=want_dx, B=B, T_in=Tout, T_out=(Tin - p + 1) // 2, M=Cin,
+                        C0=M, taps=[(p + pl - j) // 2 for j in js], out_tstride=2, out_toffset=p, T_store=Tin)
+    else:
+        xd = x.double().requires_grad_(True)
+        y = Fn.conv1d(Fn.pad(xd, (pl, ks - 2 - pl)), w.permute(2, 1, 0).double(), None, stride=2)
+        want_dx, = torch.autograd.grad(y, xd, dy.double())
+    assert torch.isfinite(dx).all()
+    assert (dx.double() - want_dx.double()).abs().max().item() <= tol * want_dx.abs().max().item()
+
+
 @pytest.mark.parametrize('half', [0, 1])
 def test_head_conv_f16x3_epilogue_options(K, half):
     """vqw_f16x3_out_conv epi 2 (the 1x1 convs around the stack and their input gradients): mask * (net_in + W x + bias + upsampled

@@ -51,6 +51,20 @@ def main():
             tb = timeit(lambda: K.f16x3_strided_conv(xp=dyp, wp=wtp, out=dx, B=B, T=Tout, Cin=F, M=F, ks=ks, pad_left=pl, dgrad=True,
                                                      w_scale_inv=1 / 16.0, shape=shape))
             row.append('shape %d fwd %6.1f us dgrad %6.1f us |' % (shape, tf, tb))
+        sslab = torch.empty(256 * 65536, device=DEV)
+        cnt = torch.zeros(1024, dtype=torch.int32, device=DEV)
+        if os.environ.get('SCONV_SPLIT_SWEEP', '1') != '0':
+            for shape in (2,):
+                for S in (0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 15):
+                    res = []
+                    for dg in (False, True):
+                        kw = dict(xp=dyp, wp=wtp, out=dx, dgrad=True) if dg else dict(xp=xp, wp=wp, out=out, save_r=r, bias=bias, bn_scale=bias, bn_shift=bias, relu=True)
+                        try:
+                            res.append('%6.1f' % timeit(lambda: K.f16x3_strided_conv(B=B, T=Tout, Cin=F, M=F, ks=ks, pad_left=pl, w_scale_inv=1 / 16.0,
+                                                                                     shape=0 if S == 0 else shape, split_slab=sslab, split_counters=cnt, ksplit=S, **kw)))
+                        except RuntimeError:
+                            res.append('   n/a')
+                    print('   T_out %4d split: shape %d ksplit %2d fwd %s us dgrad %s us' % (Tout, shape, S, res[0], res[1]), flush=True)
         t32 = timeit(lambda: K.conv_gemm(x0=x, w=w, bias=bias, out0=out, save0=r, scale=bias, shift=bias, B=B, T_in=Tin, T_out=Tout, M=F, C0=F,
                                          in_stride=2, taps=[j - pl for j in range(ks)], out_relu=True))
         row.append('fp32 engine fwd %6.1f us' % t32)

@@ -84,6 +84,8 @@ class F16x3SconvDesc(C.Structure):
         ('x_scale', _fp), ('w_scale', _fp), ('w_scale_inv', C.c_float),
         ('B', C.c_int32), ('T', C.c_int32), ('Cin', C.c_int32), ('M', C.c_int32), ('ks', C.c_int32), ('pad_left', C.c_int32),
         ('relu', C.c_int32), ('dgrad', C.c_int32), ('shape', C.c_int32),
+        ('split_slab', _fp), ('split_slab_floats', C.c_int64), ('split_counters', _fp), ('split_counters_n', C.c_int32),
+        ('ksplit', C.c_int32),
     ]
 
 

@@ -283,6 +283,7 @@ struct LoopGeom {
     //   input gradient of output parity r: tj0 = (r + pad_left) & 1, tjstep = 2, toff = r + pad_left, tsgn = +1, ts2d = 0.
     // n0 may lie anywhere in the flat (batch, time) row space: rows outside the lane's own batch row read as zero.
     int wks, tj0, tjstep, toff, tsgn, ts2d;
+    int sb, sn;      // TAB: this block's K steps [sb, sb + sn) of the ks * Cin / 16 (split-K of the short encoder layers); sn even
 };
 
 // acc[i][j] += W[m_row0 + 32 i .., :] X[:, n0 + 64 wv + 32 j ..]: MR x 2 accumulator tiles per wave, operands through
@@ -316,7 +317,7 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem,
     constexpr int NSTG_ = DEPTH + 2, STGB = X3Shape<MR>::STAGE_BYTES, BOFF = MR * 2 * 1024;      // (DEPTH: stages of requests in flight)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int KCA = (TAB ? g.wks : g.ks) * g.Cin / 8, KCB = g.Cin / 8, spt = g.Cin / 16;   // spt: K steps per tap
-    const int nsteps = g.ks * spt;
+    const int nsteps = TAB ? g.sn : g.ks * spt;
     const __amdgpu_buffer_rsrc_t ra = vqw_make_rsrc(g.wp, (unsigned)((size_t)2 * KCA * g.M * 16));
     // One buffer resource per activation plane, based at the contraction's first chunk: 32-bit offsets then only span the
     // chunks this contraction reads (checked by the callers: Cin / 8 * NB * 16 < 2 GiB), not the planes tensor -- the gated planes
@@ -344,7 +345,8 @@ __device__ __forceinline__ void f16x3_mainloop(f32x16 (&acc)[MR][2], char* smem,
         trow[i] = TAB ? (g.n0 + tile * 32 + l31) % g.T : g.t0 + tile * 32 + l31;      // time of this lane's activation row
     }
     f32x4 rgA[NA + NBP], rgB[NA + NBP];
-    auto rissue = [&](int s, f32x4 (&rg)[NA + NBP]) {
+    auto rissue = [&](int s_, f32x4 (&rg)[NA + NBP]) {
+        const int s = TAB ? s_ + g.sb : s_;
 #if VQW_X3_TAP_MINOR
         // K order: channel chunk outermost, taps innermost -- the taps of one chunk read the same activation lines a few rows apart,
         // in consecutive steps instead of Cin / 16 steps apart, while they are still in L2 (HBM reads of the gate conv d=8: 172 -> 104 MB)
@@ -834,10 +836,84 @@ __global__ __launch_bounds__(256, MR == 8 ? 1 : 2) void gate_bwd_f16x3_kernel(co
 struct SconvArgs {
     vqw_f16x3_sconv_desc d;
     int NB;
+    int S;           // SPLIT: K splits per tile (1: only the parities of an input gradient are spread over blocks)
 };
-// Block shapes: MR = 4 / DEPTH 1 (128 rows, two blocks per CU), MR = 4 / DEPTH 2 (one block per CU with two stages of requests
-// in flight: launches of <= CUs blocks, where nothing else hides the operand latency), MR = 8 / DEPTH 2 (256 rows).
-template <int MR, int DEPTH, bool DGRAD>
+
+// Split-K of a conv tile (SPLIT): the S blocks of a tile each run 1/S of the K steps and put their partial accumulators into the slab
+// (in register order: 16 bytes per lane, coalesced); the block that arrives LAST at the tile's ticket counter adds the S partial tiles
+// up in split order -- its own included, so the sum does not depend on who came last: results stay bitwise reproducible -- and runs
+// the ordinary epilogue.  The counter is back at zero when the launch ends.  Returns false for the blocks that are done.
+#ifndef VQW_SPLIT_SC1
+#define VQW_SPLIT_SC1 1
+#endif
+#ifndef VQW_SCONV_SPLIT_MAX
+#define VQW_SCONV_SPLIT_MAX 8
+#endif
+template <int MR>
+__device__ __forceinline__ bool sconv_split_fixup(f32x16 (&acc)[MR][2], float* slab, int* counter, int S, int ksp, int tid) {
+    __shared__ int s_last;
+    constexpr int TILE = MR * 32 * 256;
+    // The partial tiles cross XCDs (one L2 each): they are written through and read past the L2 (sc1, as agent-scope atomics are)
+    // instead of fencing -- a release / acquire fence pair writes back and invalidates the whole L2 of the XCD under the other
+    // blocks' main loops (measured: 12 splits of 20 K steps took longer than one block of 240).
+    const __amdgpu_buffer_rsrc_t rs = vqw_make_rsrc(slab, (unsigned)((size_t)S * TILE * 4));
+    constexpr int SC1 = VQW_SPLIT_SC1 ? 16 : 0;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const f32x4 v = f32x4{acc[i][j][v4 * 4], acc[i][j][v4 * 4 + 1], acc[i][j][v4 * 4 + 2], acc[i][j][v4 * 4 + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (ksp * TILE + ((i * 2 + j) * 4 + v4) * 1024 + tid * 4) * 4, 0, SC1);
+            }
+    if (VQW_SPLIT_SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this wave has reached memory
+    else __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == S - 1;
+        if (old == S - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    if (!VQW_SPLIT_SC1) __threadfence();
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // split order 0 .. S-1 whoever came last; the loads of the next split are in flight while one is added
+    constexpr int CH = MR * 8 < 32 ? MR * 8 : 32, NH = MR * 8 / CH;      // 16-byte entries per fetch, fetches per partial tile
+    f32x4 nx[CH];
+    auto fetch = [&](int k, int h) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+            nx[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (k * TILE + (h * CH + q) * 1024 + tid * 4) * 4, 0, SC1));
+    };
+    fetch(0, 0);
+    for (int k = 0; k < S; ++k) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            f32x4 cur[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) cur[q] = nx[q];
+            if (h + 1 < NH) fetch(k, h + 1);
+            else if (k + 1 < S) fetch(k + 1, 0);
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qq = h * CH + q;
+                    acc[qq >> 3][(qq >> 2) & 1][(qq & 3) * 4 + e] += cur[q][e];
+                }
+        }
+    }
+    return true;
+}
+
+template <int MR, int DEPTH, bool DGRAD, bool SPLIT = false>
 __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f16x3_kernel(const SconvArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int HB = 32 * MR;
@@ -845,7 +921,14 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int T = d.T, M = d.M;
     const int n_mt = M / HB;
-    const int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    int bid = vqw_xcd_remap(blockIdx.x, gridDim.x);
+    // SPLIT: block -> (K split, [parity of an input gradient,] tile), splits fastest
+    int ksp = 0, par = 0, tile_id = 0;
+    if constexpr (SPLIT) {
+        ksp = bid % a.S; bid /= a.S;
+        tile_id = bid;
+        if (DGRAD) { par = bid & 1; bid >>= 1; }
+    }
     const int mt = bid % n_mt, n0 = (bid / n_mt) * 256;
     const float winv = inv_scales(d.w_scale_inv, d.x_scale, d.w_scale);
     int bcol[2], tcol[2];
@@ -863,7 +946,10 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
     g.m_row0 = mt * HB; g.n0 = n0; g.t0 = 0; g.wks = d.ks;
     if constexpr (!DGRAD) {
         g.ks = d.ks; g.xKC = 2 * d.Cin / 8; g.tj0 = 0; g.tjstep = 1; g.toff = d.pad_left; g.tsgn = -1; g.ts2d = 1;
+        g.sn = g.ks * (d.Cin / 16) / (SPLIT ? a.S : 1); g.sb = ksp * g.sn;
         f16x3_mainloop<false, MR, true, DEPTH>(acc, smem, g, wv, lane);
+        if constexpr (SPLIT)
+            if (a.S > 1 && !sconv_split_fixup<MR>(acc, d.split_slab + (size_t)tile_id * a.S * (HB * 256), d.split_counters + tile_id, a.S, ksp, tid)) return;
         const bool hb = d.bias != nullptr, hs = d.bn_scale != nullptr, sv = d.save_r != nullptr;
         const float* bp = hb ? d.bias : reinterpret_cast<const float*>(d.wp);
         const float* sp = hs ? d.bn_scale : reinterpret_cast<const float*>(d.wp);
@@ -901,11 +987,14 @@ __global__ __launch_bounds__(256, (MR == 4 && DEPTH == 1) ? 2 : 1) void sconv_f1
     } else {
         g.xKC = d.Cin / 8; g.tjstep = 2; g.tsgn = 1; g.ts2d = 0;
 #pragma unroll 1
-        for (int r = 0; r < 2; ++r) {
+        for (int r = SPLIT ? par : 0; r < (SPLIT ? par + 1 : 2); ++r) {
             g.tj0 = (r + d.pad_left) & 1; g.toff = r + d.pad_left;
             g.ks = (d.ks - g.tj0 + 1) / 2;                       // taps of this parity (>= 1 for ks >= 2)
-            if (r) __syncthreads();                              // the first run's last stage is still being read
+            g.sn = g.ks * (d.Cin / 16) / (SPLIT ? a.S : 1); g.sb = ksp * g.sn;
+            if (!SPLIT && r) __syncthreads();                    // the first run's last stage is still being read
             f16x3_mainloop<false, MR, true, DEPTH>(acc, smem, g, wv, lane);
+            if constexpr (SPLIT)
+                if (a.S > 1 && !sconv_split_fixup<MR>(acc, d.split_slab + (size_t)tile_id * a.S * (HB * 256), d.split_counters + tile_id, a.S, ksp, tid)) return;
             float* pd[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) pd[j] = d.out + (size_t)bcol[j] * M * (2 * T) + 2 * tcol[j] + r;
@@ -1583,6 +1672,41 @@ int vqw_f16x3_strided_conv(const vqw_f16x3_sconv_desc* dp, vqw_stream_t s_) {
     VQW_CHECK(shape >= 1 && shape <= 5 && (shape != 3 || d.M % 256 == 0) && (shape != 4 || d.M % 192 == 0) && (shape != 5 || d.M % 64 == 0),
               "vqw_f16x3_strided_conv: shape is 0 (auto), 1, 2, 3 (256-row blocks: M %% 256 == 0), 4 (192-row blocks: M %% 192 == 0) or 5 (64-row blocks)");
     typedef void (*kfn_t)(SconvArgs);
+    // Split-K (scratch given): a launch of few 128-row tiles cuts each tile's K steps over S blocks -- as many as fill the chip once, the
+    // steps of every parity in even parts of at least 8 steps, at most 8 partial tiles per fix-up (256-row tiles measured slower at every
+    // split count, tools/sconv_bench.py, and their fix-up does not fit the register file).
+    if (d.split_slab && d.ksplit != 1 && (d.shape == 0 || d.shape == 2)) {
+        VQW_CHECK(d.split_counters, "vqw_f16x3_strided_conv: split_slab needs split_counters");
+        const int spt = d.Cin / 16, par = d.dgrad ? 2 : 1;
+        const int st0 = d.dgrad ? ((d.ks - (d.pad_left & 1) + 1) / 2) * spt : d.ks * spt;          // K steps of parity 0 / the forward conv
+        const int st1 = d.dgrad ? ((d.ks - ((1 + d.pad_left) & 1) + 1) / 2) * spt : st0;
+        auto fits = [&](int S) { return S >= 1 && st0 % (2 * S) == 0 && st1 % (2 * S) == 0 && st0 / S >= 8 && st1 / S >= 8; };
+        const int tiles = (d.M / 128) * nt * par;
+        int S = d.ksplit;
+        if (S == 0) {
+            // one round of blocks; tools/sconv_bench.py (us per launch, 24 tiles: S = 2 / 4 / 8 / 10 / 12 -> 82 / 54 / 47.5 / 49 / 65): a K step
+            // costs ~0.55 us, a partial tile in the fix-up ~2.5 us.  Where even two blocks per tile do not fit in one round but the unsplit
+            // launch would leave two thirds of the chip idle (the input gradient of layer 3: 78 blocks of 120 steps), up to two rounds
+            // (130 -> 90 us with three splits).
+            for (int c = 2; c <= VQW_SCONV_SPLIT_MAX; ++c) if (fits(c) && tiles * c <= cus) S = c;
+            if (S == 0 && (tiles / par) * 3 <= cus)
+                for (int c = 2; c <= VQW_SCONV_SPLIT_MAX; ++c) if (fits(c) && tiles * c <= 2 * cus) S = c;
+        }
+        if (S > 1) {
+            VQW_CHECK(fits(S), "vqw_f16x3_strided_conv: the K steps (%d / %d) do not divide into %d even parts of >= 8", st0, st1, S);
+            VQW_CHECK(tiles <= d.split_counters_n && (int64_t)tiles * S * 128 * 256 <= d.split_slab_floats,
+                      "vqw_f16x3_strided_conv: split scratch too small (%d tiles x %d splits)", tiles, S);
+            a.S = S;
+            const kfn_t kfn = d.dgrad ? sconv_f16x3_kernel<4, 2, true, true> : sconv_f16x3_kernel<4, 2, false, true>;
+            const int lds = 4 * (4 * 2 + 16) * 1024;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return vqw_set_error("vqw_f16x3_strided_conv: cannot reserve %d bytes of LDS", lds);
+            hipLaunchKernelGGL(kfn, dim3(tiles * S), dim3(256), lds, st, a);
+            VQW_LAUNCH_CHECK("vqw_f16x3_strided_conv");
+            return 0;
+        }
+    }
+    a.S = 1;
     const kfn_t kfn = d.dgrad ? (shape == 5 ? sconv_f16x3_kernel<2, 2, true> : (shape == 4 ? sconv_f16x3_kernel<6, 2, true> : (shape == 3 ? sconv_f16x3_kernel<8, 2, true> : (shape == 2 ? sconv_f16x3_kernel<4, 2, true> : sconv_f16x3_kernel<4, 1, true>))))
                               : (shape == 5 ? sconv_f16x3_kernel<2, 2, false> : (shape == 4 ? sconv_f16x3_kernel<6, 2, false> : (shape == 3 ? sconv_f16x3_kernel<8, 2, false> : (shape == 2 ? sconv_f16x3_kernel<4, 2, false> : sconv_f16x3_kernel<4, 1, false>))));
     const int mr = shape == 5 ? 2 : (shape == 4 ? 6 : (shape == 3 ? 8 : 4)), lds = (shape == 1 ? 3 : 4) * (mr * 2 + 16) * 1024;      // DEPTH + 2 stages

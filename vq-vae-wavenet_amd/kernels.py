@@ -346,10 +346,13 @@ def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, n
 
 
 def f16x3_strided_conv(*, xp, wp, out, B, T, Cin, M, ks, pad_left, w_scale_inv=1.0, bias=None, bn_scale=None, bn_shift=None,
-                       save_r=None, relu=False, dgrad=False, x_scale=None, w_scale=None, shape=0):
+                       save_r=None, relu=False, dgrad=False, x_scale=None, w_scale=None, shape=0, split_slab=None,
+                       split_counters=None, ksplit=0):
     """vqw_f16x3_strided_conv: a stride-2 conv (SAME padding, pad_left zeros in front) -> bias -> relu -> BatchNorm affine over
     space-to-depth planes of x [B][Cin][2T] (out [B][M][T]), or with dgrad its input gradient from the planes of dy [B][Cin][T]
-    (out [B][M][2T]; wp = planes of the transposed kernel)."""
+    (out [B][M][2T]; wp = planes of the transposed kernel).  split_slab (fp32 scratch) + split_counters (int32, zero before the
+    first launch): launches that would leave most of the chip idle cut the K steps of a tile over several blocks (ksplit 0 = auto,
+    1 = off, n = n blocks per tile)."""
     _need_planes(xp, 2 * Cin * B * T * (1 if dgrad else 2), 'xp')
     _need_planes(wp, 2 * ks * Cin * M, 'wp')
     _need(out, B * M * T * (2 if dgrad else 1), 'out')
@@ -367,6 +370,12 @@ def f16x3_strided_conv(*, xp, wp, out, B, T, Cin, M, ks, pad_left, w_scale_inv=1
     d.x_scale, d.w_scale, d.w_scale_inv = _slot(x_scale, 'x_scale'), _slot(w_scale, 'w_scale'), float(w_scale_inv)
     d.B, d.T, d.Cin, d.M, d.ks, d.pad_left, d.relu, d.dgrad = B, T, Cin, M, ks, pad_left, int(bool(relu)), int(bool(dgrad))
     d.shape = shape
+    if split_slab is not None:
+        if split_counters is None or split_counters.dtype != torch.int32 or split_slab.dtype != torch.float32:
+            raise ValueError('f16x3_strided_conv: split_slab (float32) needs split_counters (int32)')
+        d.split_slab, d.split_slab_floats = split_slab.data_ptr(), split_slab.numel()
+        d.split_counters, d.split_counters_n = split_counters.data_ptr(), split_counters.numel()
+    d.ksplit = ksplit
     L.check(L.lib().vqw_f16x3_strided_conv(C.byref(d), L.stream()))
 
 

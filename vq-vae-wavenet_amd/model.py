@@ -473,7 +473,7 @@ class VQVAE:
                 K.f16x3_split_activations(ws['X'][i - 1], epl, B, F, Tin, scale_dev=es[i:i + 1], mode=K.X3_S2D)
                 K.f16x3_strided_conv(xp=epl, wp=ws['ewp'][i - 1], out=ws['X'][i], save_r=ws['r'][i] if save else None,
                                      B=B, T=Tout, Cin=F, M=F, ks=5, pad_left=pl, bias=P['enc_b'][i], bn_scale=sc[i * F:(i + 1) * F],
-                                     bn_shift=sh[i * F:(i + 1) * F], relu=True, x_scale=es[i:i + 1], w_scale=es[0:1])
+                                     bn_shift=sh[i * F:(i + 1) * F], relu=True, x_scale=es[i:i + 1], w_scale=es[0:1], **self._sconv_split(ws))
             elif nsplit > 1:
                 # short layer (T_out down to 104): too few tiles for 256 CUs, but K = 5*768 is long: split-K into the
                 # output buffer (plain STORE + atomics), then relu / save / BatchNorm affine as a second, tiny pass
@@ -510,6 +510,18 @@ class VQVAE:
             ws['wslab'] = A.empty(cus * 65536, device=self.dev)
             ws['_poison'].append(ws['wslab'])
         return ws['wslab']
+
+    def _sconv_split(self, ws):
+        """Scratch of the strided convs' split-K launches (encoder layers 3-5: 24..78 tiles of 240 K steps on 256 CUs): partial tiles
+        of one launch (at most two rounds of 128-row blocks) and the tiles' ticket counters, which every launch leaves at zero."""
+        if os.environ.get('VQW_SCONV_SPLIT', '1') == '0':
+            return {}
+        if 'sslab' not in ws:
+            cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            ws['sslab'] = A.empty(cus * 65536, device=self.dev)
+            ws['_poison'].append(ws['sslab'])
+            ws['scount'] = torch.zeros(1024, dtype=torch.int32, device=self.dev)
+        return {'split_slab': ws['sslab'], 'split_counters': ws['scount']}
 
     def _side_stream(self):
         if self._side is None:
@@ -1155,7 +1167,7 @@ class VQVAE:
                 if not w_planes:
                     K.f16x3_split_activations(dX, ws['eplanes'], B, F, Ti, scale_dev=es[5 + i:6 + i], mode=0)
                 K.f16x3_strided_conv(xp=ws['edp'][i] if w_planes else ws['eplanes'], wp=ws['ewtp'][i - 1], out=ws['dX'][i - 1], B=B, T=Ti, Cin=F, M=F, ks=5,
-                                     pad_left=pl, dgrad=True, x_scale=es[5 + i:6 + i], w_scale=es[0:1])
+                                     pad_left=pl, dgrad=True, x_scale=es[5 + i:6 + i], w_scale=es[0:1], **self._sconv_split(ws))
                 continue
             # transposed conv: output times tau = 2u+p get taps j with j = p + pad_left (mod 2)
             nsplit = self._short_layer_split(F, (Tin + 1) // 2, B)
