@@ -253,6 +253,13 @@ int vqw_softmax_xent_bwd(const float* logits, const int32_t* labels, float* dlog
 int vqw_adam_ema_step(float* param, const float* grad, float* m, float* v, float* ema,
                       size_t n, float lr_t, float beta1, float beta2, float eps,
                       float decay, float grad_scale, vqw_stream_t s);
+/* The same step behind a device-side guard: with *skip != 0 (a device int32 read when the kernel RUNS) nothing is
+ * changed.  The guarded fp16x3 engine enqueues its optimiser this way when the host reads the step's range flag one
+ * step late (model.defer_guard): a flagged step and everything enqueued behind it leave parameters, Adam slots and EMA
+ * shadows untouched and are then repeated in order.  skip NULL = vqw_adam_ema_step.                                */
+int vqw_adam_ema_step_guarded(float* param, const float* grad, float* m, float* v, float* ema,
+                              size_t n, float lr_t, float beta1, float beta2, float eps,
+                              float decay, float grad_scale, const int32_t* skip, vqw_stream_t s);
 
 /* ------------------------------------------------------------------------------------
  * Fast autoregressive generation -- wavenet.py:103-172, wavenet_ops.py:147-267,
@@ -352,6 +359,9 @@ int vqw_ar_decode_destroy(vqw_ar_decoder* h);
 int vqw_f16x3_amax(const float* x, int64_t rows, int cols, int64_t ld, int64_t mstride, int count, uint32_t* amax,
                    int32_t* flag, vqw_stream_t s);
 int vqw_f16x3_update_scales(uint32_t* amax, float* scale, int n, int target_exp, int reset, int32_t* flag, vqw_stream_t s);
+/* ... behind a device-side guard (as vqw_adam_ema_step_guarded): with *skip != 0 when the kernel runs, nothing is touched */
+int vqw_f16x3_update_scales_guarded(uint32_t* amax, float* scale, int n, int target_exp, int reset, int32_t* flag,
+                                    const int32_t* skip, vqw_stream_t s);
 
 /* scale * scale_dev[0] * x [B][C][T] fp32 -> planes [2][C/8][B*T][8] fp16; C % 8 == 0.  scale: 1 for activations, a
  * power of two that lifts a gradient tensor into fp16's range (undone through w_scale_inv / x_scale of the consumer) */

@@ -104,13 +104,17 @@ def main():
     if mode == 'rccl1':
         return rccl_one_rank(pkg, out_dir)
     dist.init_process_group(backend, rank=rank, world_size=world)
-    m, w, P, x, spk = guard_problem() if mode == 'guard' else shared_problem()
+    m, w, P, x, spk = guard_problem() if mode.startswith('guard') else shared_problem()
     model = pkg.model.VQVAE(m, w, 10, device='cuda', seed=0)
     model.load_named(P)
     model.grad_sync = pkg.parallel.GradAllReduce(model.grad)
+    model.defer_guard = mode == 'guard_deferred'       # the flag is MAX-all-reduced on the device and read by finish_steps()
     per = x.shape[0] // world
     rows = slice(rank * per, (rank + 1) * per)
     ws = model.train_step(x[rows].contiguous().cuda(), spk[rows].contiguous().cuda())
+    if model.defer_guard:
+        assert len(model._pending) == 1 and model.x3_fallbacks == 0
+        model.finish_steps()               # (ws is the cached workspace: it now holds the repeated step)
     torch.cuda.synchronize()
     torch.save({'grad_sum': model.grad.cpu(), 'flat': model.flat.cpu(), 'ema': model.ema.cpu(),
                 'loss': torch.tensor(model.losses(ws)), 'fallbacks': torch.tensor(model.x3_fallbacks),

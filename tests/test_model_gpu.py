@@ -314,6 +314,50 @@ def test_guarded_f16x3_engine_adversarial_ranges(pkg, monkeypatch, what):
         assert model.x3_fallbacks >= 1 and not used[0] and used[-1], (model.x3_fallbacks, used)
 
 
+def test_deferred_guard_matches_immediate(pkg, monkeypatch):
+    """model.defer_guard (bench.py / train.py): the range flag of step k is read after step k + 1 has been enqueued, the optimiser
+    runs behind a device-side guard (vqw_adam_ema_step_guarded).  Six steps on different batches with two flagged steps -- the
+    second and the fourth: a layer-input scale pushed 2^24 up behind the engine's back, so that a speculative step sits behind
+    each flagged one; the last step is resolved by finish_steps -- against the same six steps in the immediate mode: the same
+    steps are repeated on the fp32 engine, step counter / engine counters are equal, parameters, Adam slots, EMA shadows and
+    plane scales agree as closely as two runs of the immediate mode do."""
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    P = M.init_params(m, w, 109, seed=3, randomize_all=True)
+    batches = []
+    for i in range(6):
+        x, spk, _ = M.synthetic_batch(1, 1024, 109, 4321 + i)
+        batches.append((x[:, :, 0].contiguous().cuda(), spk.cuda()))
+    models = []
+    for defer in (False, True):
+        model = _guarded_model(pkg, monkeypatch, P, m, w)
+        model.defer_guard = defer
+        trace = []
+        for i, (xd, sd) in enumerate(batches):
+            if i in (1, 3):
+                model.x3_scale[model.SL['X'] + 2] *= 2.0 ** 24
+            model.train_step(xd, sd)
+            trace.append((model.global_step, model.x3_fallbacks))
+        if defer:
+            assert model._pending, 'the last deferred step should still be unresolved here'
+        model.finish_steps()
+        assert not model._pending and int(model.x3_void.item()) == 0
+        models.append((model, trace))
+    (a, ta), (b, tb) = models
+    assert a.x3_fallbacks == 2 and b.x3_fallbacks == 2, (a.x3_fallbacks, b.x3_fallbacks)
+    assert a.global_step == b.global_step == 6 and a.x3_steps == b.x3_steps == 4
+    assert ta[-1] == (6, 2) and tb != ta          # (the deferred run learns of a flagged step one call late)
+    # Bars: two runs of the IMMEDIATE mode already differ from each other by 3e-4 (parameters) / 6e-2 (Adam's first moments) rel. L2
+    # after these six steps and by a factor of two in one or two plane scales (tools/defer_diag.py: the fp32 engine's atomics and
+    # the bias sums' are summation-order noise, and Adam turns noise on a near-zero gradient into a step of +-lr); the deferred
+    # mode is held to that distance, a voided step that leaked into the state would show as errors of order one.
+    ratio = a.x3_scale / b.x3_scale
+    assert float(ratio.max()) <= 4.0 and float(ratio.min()) >= 0.25, 'plane scales: immediate %s deferred %s' % (a.x3_scale.tolist(), b.x3_scale.tolist())
+    for name, bar in (('flat', 3e-3), ('ema', 3e-3), ('adam_v', 2e-1), ('adam_m', 3e-1)):
+        ta_, tb_ = getattr(a, name), getattr(b, name)
+        assert torch.isfinite(tb_).all(), name
+        assert l2err(tb_, ta_) < bar, '%s: deferred vs immediate rel. L2 %.3e' % (name, l2err(tb_, ta_))
+
+
 @pytest.mark.parametrize('B,T', [(1, 1280), (2, 6400)])
 def test_bf16_engine_encoder_2019(pkg, monkeypatch, B, T):
     """BASELINE.json configs[4]: the '2019' encoder (MFCC front end, T % 320 == 0) with the decoder's contractions on the

@@ -86,6 +86,30 @@ def test_range_flag_of_one_rank_makes_every_rank_repeat_the_step(pkg, tmp_path):
     assert float((g_avg - g_full).norm()) < 1e-4 * float(g_full.norm()), 'sum / world != full-batch gradient'
 
 
+def test_deferred_range_flag_under_data_parallelism(pkg, tmp_path):
+    """The same problem with model.defer_guard (train.py / bench.py): the flag is MAX-all-reduced on the device, latched into
+    the sticky guard in front of the optimiser, and read by the host afterwards -- both ranks find the step voided, repeat it on
+    the fp32 engine and end with bit-identical parameters, equal to the immediate mode's."""
+    run_ranks([os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path), 'gloo', 'guard_deferred'], 2)
+    r0 = torch.load(str(tmp_path / 'rank0.pt'), weights_only=True)
+    r1 = torch.load(str(tmp_path / 'rank1.pt'), weights_only=True)
+    assert int(r0['fallbacks']) == 1 and int(r1['fallbacks']) == 1, 'both ranks must repeat the step'
+    assert not bool(r0['x3_used']) and not bool(r1['x3_used'])
+    assert torch.isfinite(r0['grad_sum']).all() and torch.isfinite(r0['flat']).all()
+    assert torch.equal(r0['grad_sum'], r1['grad_sum']), 'ranks hold different reduced gradients'
+    assert torch.equal(r0['flat'], r1['flat']) and torch.equal(r0['ema'], r1['ema']), 'ranks diverged after the step'
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_worker
+    m, w, P, x, spk = dp_worker.guard_problem()
+    full = pkg.model.VQVAE(m, w, 10, device='cuda', seed=0)
+    full.load_named(P)
+    full.train_step(x.cuda(), spk.cuda())
+    g_full, g_avg = full.grad.cpu().double(), r0['grad_sum'].double() / 2
+    assert float((g_avg - g_full).norm()) < 1e-4 * float(g_full.norm()), 'sum / world != full-batch gradient'
+    big = g_full.abs() > 1e-3 * g_full.abs().max()
+    assert float((r0['flat'] - full.flat.cpu())[big].abs().max()) < 1e-5
+
+
 def test_one_rank_on_rccl_runs_the_bucketed_exchange(pkg, tmp_path):
     """RCCL itself, on the one GPU this box has: a fresh child with WORLD_SIZE=1, backend nccl, GradAllReduce(force=True).
     The decoder bucket, the per-layer encoder buckets and the rest are all-reduced on the side stream by the real

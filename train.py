@@ -81,6 +81,7 @@ def main():
             model.load_state_dict(torch.load(args.restore_path, map_location='cpu', weights_only=True))
     if world > 1:
         model.grad_sync = pkg.parallel.GradAllReduce(model.grad)
+    model.defer_guard = os.environ.get('VQW_DEFER_GUARD', '1') != '0'     # the engine's range flag is read one step late (no host sync per step)
     gs, lr = model.global_step, model.lr_at(model.global_step)
     if rank == 0:
         print('[restore] last global step: %d, learning rate: %.5f' % (gs, lr))

@@ -138,6 +138,7 @@ SIGNATURES = {
     'vqw_softmax_xent_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     'vqw_softmax_xent_bwd': (_i, [_fp, _fp, _fp, _f, _i, _i, _i, _fp]),
     'vqw_adam_ema_step': (_i, [_fp, _fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _f, _fp]),
+    'vqw_adam_ema_step_guarded': (_i, [_fp, _fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _f, _fp, _fp]),
     'vqw_ar_decode_create': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i]),
     'vqw_ar_decode_create_ex': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i, _i]),
     'vqw_ar_decode_reset': (_i, [_fp, _fp]),
@@ -150,6 +151,7 @@ SIGNATURES = {
     'vqw_ar_decode_destroy': (_i, [_fp]),
     'vqw_f16x3_amax': (_i, [_fp, _i64, _i, _i64, _i64, _i, _fp, _fp, _fp]),
     'vqw_f16x3_update_scales': (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
+    'vqw_f16x3_update_scales_guarded': (_i, [_fp, _fp, _i, _i, _i, _fp, _fp, _fp]),
     'vqw_f16x3_split_activations': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _i, _fp, _fp, _fp, _i, _fp]),
     'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _i, _fp]),
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),

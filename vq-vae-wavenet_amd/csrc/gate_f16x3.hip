@@ -178,9 +178,9 @@ __global__ void amax_kernel(const float* __restrict__ x, long rows, int cols, lo
 
 // scale[i] = 2^(target_exp - 1 - floor(log2(amax[i]))): amax * scale in [2^(target_exp-1), 2^target_exp); a slot that saw
 // nothing (amax == 0) keeps its scale; reset: amax[i] = 0 afterwards (the next step collects afresh)
-__global__ void update_scales_kernel(unsigned* amax, float* scale, int n, int target_exp, int reset, int* flag) {
+__global__ void update_scales_kernel(unsigned* amax, float* scale, int n, int target_exp, int reset, int* flag, const int* skip) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (skip && *skip)) return;      // (skip: a voided step of the deferred guard leaves scales and max-abs slots alone)
     const unsigned b = amax[i];
     if (b >= 0x7f800000u) {                  // inf / NaN was seen
         if (flag) atomicOr(flag, 1);
@@ -1501,12 +1501,17 @@ int vqw_f16x3_amax(const float* x, int64_t rows, int cols, int64_t ld, int64_t m
     return 0;
 }
 
-int vqw_f16x3_update_scales(uint32_t* amax, float* scale, int n, int target_exp, int reset, int32_t* flag, vqw_stream_t s_) {
+int vqw_f16x3_update_scales_guarded(uint32_t* amax, float* scale, int n, int target_exp, int reset, int32_t* flag, const int32_t* skip,
+                                    vqw_stream_t s_) {
     VQW_CHECK(amax && scale && n > 0, "vqw_f16x3_update_scales: null pointer");
     VQW_CHECK(target_exp >= 1 && target_exp <= 15, "vqw_f16x3_update_scales: target_exp must be in 1..15 (fp16 holds |x| < 2^16)");
-    hipLaunchKernelGGL(update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)s_, amax, scale, n, target_exp, reset, flag);
+    hipLaunchKernelGGL(update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)s_, amax, scale, n, target_exp, reset, flag, skip);
     VQW_LAUNCH_CHECK("vqw_f16x3_update_scales");
     return 0;
+}
+
+int vqw_f16x3_update_scales(uint32_t* amax, float* scale, int n, int target_exp, int reset, int32_t* flag, vqw_stream_t s_) {
+    return vqw_f16x3_update_scales_guarded(amax, scale, n, target_exp, reset, flag, nullptr, s_);
 }
 
 int vqw_f16x3_split_activations(const float* x, void* planes, int B, int C, int T, float scale, int kc0, int KC,

@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
 __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                 float* __restrict__ m, float* __restrict__ v,
                                 float* __restrict__ ema, size_t n4, size_t n, float lr_t, float b1,
-                                float b2, float eps, float decay, float gs) {
+                                float b2, float eps, float decay, float gs, const int* __restrict__ skip) {
+    if (skip && *skip) return;          // a voided step (vqw_adam_ema_step_guarded): nothing changes
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
         f32x4 P = reinterpret_cast<f32x4*>(p)[i];
@@ -697,16 +698,22 @@ extern "C" int vqw_softmax_xent_bwd(const float* logits, const int32_t* labels, 
     return 0;
 }
 
-extern "C" int vqw_adam_ema_step(float* param, const float* grad, float* m, float* v, float* ema, size_t n,
-                                 float lr_t, float beta1, float beta2, float eps, float decay,
-                                 float grad_scale, vqw_stream_t s) {
+extern "C" int vqw_adam_ema_step_guarded(float* param, const float* grad, float* m, float* v, float* ema, size_t n,
+                                         float lr_t, float beta1, float beta2, float eps, float decay,
+                                         float grad_scale, const int32_t* skip, vqw_stream_t s) {
     VQW_CHECK(param && grad && m && v && ema, "vqw_adam_ema_step: null pointer");
     if (n == 0) return 0;
     const uintptr_t al = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
                          reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
                          reinterpret_cast<uintptr_t>(ema);
     const size_t n4 = (al & 15u) ? 0 : n / 4;
-    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n4 ? n4 : n, 256)), dim3(256), 0, (hipStream_t)s, param, grad, m, v, ema, n4, n, lr_t, beta1, beta2, eps, decay, grad_scale);
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n4 ? n4 : n, 256)), dim3(256), 0, (hipStream_t)s, param, grad, m, v, ema, n4, n, lr_t, beta1, beta2, eps, decay, grad_scale, skip);
     VQW_LAUNCH_CHECK("vqw_adam_ema_step");
     return 0;
+}
+
+extern "C" int vqw_adam_ema_step(float* param, const float* grad, float* m, float* v, float* ema, size_t n,
+                                 float lr_t, float beta1, float beta2, float eps, float decay,
+                                 float grad_scale, vqw_stream_t s) {
+    return vqw_adam_ema_step_guarded(param, grad, m, v, ema, n, lr_t, beta1, beta2, eps, decay, grad_scale, nullptr, s);
 }

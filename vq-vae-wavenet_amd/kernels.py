@@ -253,14 +253,15 @@ def f16x3_amax(x, amax, *, rows=None, cols=None, ld=None, mstride=0, count=1, fl
     L.check(L.lib().vqw_f16x3_amax(L.ptr(x), rows, cols, ld, mstride, count, L.ptr(amax), _slot(flag, 'flag', torch.int32), L.stream()))
 
 
-def f16x3_update_scales(amax, scale, *, target_exp, reset=True, flag=None):
+def f16x3_update_scales(amax, scale, *, target_exp, reset=True, flag=None, skip=None):
     """scale[i] = the power of two that puts amax[i] into [2^(target_exp-1), 2^target_exp) (slots that saw nothing keep their scale);
-    reset: amax[i] = 0 afterwards; a non-finite amax raises `flag`."""
+    reset: amax[i] = 0 afterwards; a non-finite amax raises `flag`; skip (device int32): non-zero when the kernel runs = nothing is touched."""
     n = amax.numel()
     if amax.dtype != torch.int32 or scale.dtype != torch.float32 or scale.numel() != n:
         raise ValueError('amax int32 [n], scale float32 [n]')
     L.require_cuda(amax, scale)
-    L.check(L.lib().vqw_f16x3_update_scales(L.ptr(amax), L.ptr(scale), n, target_exp, int(reset), _slot(flag, 'flag', torch.int32), L.stream()))
+    L.check(L.lib().vqw_f16x3_update_scales_guarded(L.ptr(amax), L.ptr(scale), n, target_exp, int(reset), _slot(flag, 'flag', torch.int32),
+                                                    _slot(skip, 'skip', torch.int32), L.stream()))
 
 
 def f16x3_split_activations(x, planes, B, Cc, T, scale=1.0, kc0=0, KC=0, scale_dev=None, amax=None, flag=None, mode=None):
@@ -583,10 +584,13 @@ def softmax_xent_bwd(logits, labels, *, dlogits, grad_scale=1.0):
 
 
 def adam_ema_step(param, grad, m, v, ema, *, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, decay=0.999,
-                  grad_scale=1.0):
+                  grad_scale=1.0, skip=None):
+    """skip: device int32 read when the kernel runs; non-zero = the step changes nothing (vqw_adam_ema_step_guarded)."""
     n = param.numel()
     for t, nm in ((grad, 'grad'), (m, 'm'), (v, 'v'), (ema, 'ema')):
         _need(t, n, nm)
-    L.check(L.lib().vqw_adam_ema_step(L.ptr(param), L.ptr(grad), L.ptr(m), L.ptr(v), L.ptr(ema), n, float(lr_t),
-                                      float(beta1), float(beta2), float(eps), float(decay), float(grad_scale),
-                                      L.stream()))
+    if skip is not None and (skip.dtype != torch.int32 or skip.numel() < 1 or not skip.is_cuda):
+        raise ValueError('adam_ema_step: skip must be a device int32')
+    L.check(L.lib().vqw_adam_ema_step_guarded(L.ptr(param), L.ptr(grad), L.ptr(m), L.ptr(v), L.ptr(ema), n, float(lr_t),
+                                              float(beta1), float(beta2), float(eps), float(decay), float(grad_scale),
+                                              L.ptr(skip), L.stream()))

@@ -13,6 +13,7 @@ variable names and shapes.
 import json
 import math
 import os
+import time
 import sys
 from collections import OrderedDict
 
@@ -150,6 +151,10 @@ class VQVAE:
         self.head_x3 = os.environ.get('VQW_HEAD_X3', '1') != '0'
         self.x3_amax = torch.zeros(self.SL['N'], dtype=torch.int32, device=self.dev)
         self.x3_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.x3_void = torch.zeros(1, dtype=torch.int32, device=self.dev)      # deferred mode: a flagged step is waiting to be repeated
+        self.defer_guard = os.environ.get('VQW_DEFER_GUARD', '0') == '1'       # read the range flag one step late (train_step)
+        self._pending, self._void_host, self._void_slot = [], None, 0
+        self.host_enqueue_ms = None
 
     # ------------------------------------------------------------------ parameter layout
     def _build_layout(self):
@@ -729,6 +734,7 @@ class VQVAE:
         fp16x3 engine the activation planes are scaled with the PREVIOUS training step's max-abs values (1.0 on a fresh model):
         train_step reads the range flag and repeats a flagged step on the fp32 engine; a bare forward() does not.  This one
         does: the flag is zeroed, read after the pass (one host sync) and a flagged pass is repeated on the fp32 engine."""
+        self.finish_steps()
         if not self.x3_guard:
             return self.forward(x, spk, compute_grad_seed)
         self.x3_flag.zero_()
@@ -743,6 +749,7 @@ class VQVAE:
 
     def losses(self, ws):
         """(loss, reconstruction, vq, commitment) as python floats (synchronises)."""
+        self.finish_steps()
         v = self.loss_buf.tolist()
         recon = v[0] / (ws['B'] * ws['T'])
         vq = v[1] / (ws['B'] * ws['Tz'] * self.D) if self.use_vq else 0.0   # model.py:100
@@ -755,6 +762,7 @@ class VQVAE:
         `_u` / `_v` are the mean / variance over the last (feature) axis, as tf.nn.moments(x, [-1]).  The reference's
         'distances' histogram is over the [B, Tz, K] tensor this build never materialises; 'distances_min' (the distance to
         the chosen code) stands in for it.  Synchronises."""
+        self.finish_steps()
         def hist(t):
             t = t.detach().float().reshape(-1)
             lo, hi = float(t.min()), float(t.max())
@@ -1199,12 +1207,12 @@ class VQVAE:
                 lr = value
         return lr
 
-    def apply_gradients(self, grad_scale=1.0):
-        """TF-1.x Adam + EMA(0.999) (model.py:116-128)."""
+    def apply_gradients(self, grad_scale=1.0, skip=None):
+        """TF-1.x Adam + EMA(0.999) (model.py:116-128).  skip: device int32, non-zero when the kernel runs = nothing changes."""
         t = self.global_step + 1
         lr = self.lr_at(self.global_step)
         lr_t = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
-        K.adam_ema_step(self.flat, self.grad, self.adam_m, self.adam_v, self.ema, lr_t=lr_t, grad_scale=grad_scale)
+        K.adam_ema_step(self.flat, self.grad, self.adam_m, self.adam_v, self.ema, lr_t=lr_t, grad_scale=grad_scale, skip=skip)
         self.global_step = t
         return lr
 
@@ -1212,20 +1220,31 @@ class VQVAE:
         """One sess.run(train_op) (train.py:104-114).  on_forward(ws): called between the forward and the backward pass of the
         step that is kept (tests snapshot the relu inputs there: backward overwrites them in place).  With self.grad_sync set (data parallel)
         the flat gradient is sum-all-reduced over RCCL in buckets that overlap the backward pass, and averaged.
-        Guarded fp16x3 engine: the step's range flag is read before the optimiser runs (one host sync per step); a
-        step whose planes left fp16's range is repeated on the fp32 engine, which also measures the max-abs values the
-        next step's scales come from."""
-        if self.x3_guard:
-            self.x3_flag.zero_()
-        ws = self.forward(x, spk)
-        if on_forward is not None:
-            on_forward(ws)
-        self.backward(x, spk, ws)
-        world = self.grad_sync.finish() if self.grad_sync is not None else 1
-        if self.bf16 and ws.get('x3_used'):
-            self.x3_steps += 1
-        if self.x3_guard and (ws.get('x3_used') or ws.get('enc_x3')):
-            if self._x3_overflowed():
+        Guarded fp16x3 engine: a step whose planes left fp16's range is repeated on the fp32 engine, which also measures the
+        max-abs values the next step's scales come from.  The step's range flag is read before the optimiser runs (one host sync
+        per step) -- or, with self.defer_guard (bench.py, train.py), one step LATE: see _train_step_deferred."""
+        if self.defer_guard and self.x3_guard and on_forward is None:
+            return self._train_step_deferred(x, spk)
+        self.finish_steps()
+        return self._train_step_now(x, spk, on_forward)
+
+    def _train_step_now(self, x, spk, on_forward=None, known_flagged=False):
+        """The step with its range flag read on the spot.  known_flagged: the fp16x3 attempt of this step already ran and
+        raised the flag (deferred mode): go straight to the repeat."""
+        guarded, world, ws = self.x3_guard and known_flagged, 1, None
+        if not known_flagged:
+            if self.x3_guard:
+                self.x3_flag.zero_()
+            ws = self.forward(x, spk)
+            if on_forward is not None:
+                on_forward(ws)
+            self.backward(x, spk, ws)
+            world = self.grad_sync.finish() if self.grad_sync is not None else 1
+            if self.bf16 and ws.get('x3_used'):
+                self.x3_steps += 1
+            guarded = bool(self.x3_guard and (ws.get('x3_used') or ws.get('enc_x3')))
+        if guarded:
+            if known_flagged or self._x3_overflowed():
                 self.x3_fallbacks += 1
                 self._x3_active = False
                 try:
@@ -1249,6 +1268,64 @@ class VQVAE:
         self.apply_gradients(1.0 / world)
         return ws
 
+    def _train_step_deferred(self, x, spk):
+        """The guarded step without a host sync on its path.  Reading the range flag before the optimiser drains the launch queue
+        once per step, and the host then needs ~1.2 ms of the next step to get ahead of the GPU again (bench.py's shape: 26.6 ->
+        25.5 ms).  Here the verdict stays on the device: the flag is latched into the sticky x3_void, the optimiser is enqueued
+        behind that guard (vqw_adam_ema_step_guarded, vqw_f16x3_update_scales_guarded: a voided step changes no parameter, Adam slot,
+        EMA shadow or plane scale), x3_void is
+        copied to pinned host memory, and the host looks at the copy of step k only after it has enqueued step k + 1.  If step k
+        was flagged, it and step k + 1 (enqueued behind it, voided by the sticky guard) have changed nothing: the guard is
+        cleared, the step counter rewound, step k is repeated on the fp32 engine and step k + 1 is run again -- parameters after
+        every step are bit-identical to the immediate mode (tests/test_model_gpu.py::test_deferred_guard_matches_immediate).
+        Callers keep x / spk unchanged until the step is resolved (finish_steps(), or the next-but-one train_step) and call
+        finish_steps() before reading what a step left behind (losses, gradients, parameters; state_dict() / encode() do)."""
+        t_host = time.perf_counter()
+        self.x3_flag.zero_()
+        ws = self.forward(x, spk)
+        self.backward(x, spk, ws)
+        world = self.grad_sync.finish() if self.grad_sync is not None else 1
+        if not (ws.get('x3_used') or ws.get('enc_x3')):       # nothing on the guarded engine in this workspace
+            self.apply_gradients(1.0 / world)
+            return ws
+        if self.grad_sync is not None and self.grad_sync.active:
+            self.grad_sync.all_reduce_max(self.x3_flag)       # every rank takes the same branch
+        torch.maximum(self.x3_void, self.x3_flag, out=self.x3_void)
+        n0 = self.SL['G']
+        K.f16x3_update_scales(self.x3_amax[n0:], self.x3_scale[n0:], target_exp=13, skip=self.x3_void)
+        gs0 = self.global_step
+        self.apply_gradients(1.0 / world, skip=self.x3_void)
+        if self._void_host is None:
+            self._void_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        slot = self._void_slot
+        self._void_slot = (slot + 1) % 4
+        self._void_host[slot:slot + 1].copy_(self.x3_void, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append({'x': x, 'spk': spk, 'gs0': gs0, 'ev': ev, 'slot': slot})
+        self.host_enqueue_ms = (time.perf_counter() - t_host) * 1e3        # what the host needs to enqueue one step (it must stay below the step's GPU time)
+        while len(self._pending) > 1:
+            self._resolve_oldest()
+        return ws
+
+    def _resolve_oldest(self):
+        p = self._pending[0]
+        p['ev'].synchronize()
+        if int(self._void_host[p['slot']]) == 0:
+            self._pending.pop(0)
+            self.x3_steps += 1
+            return
+        pend, self._pending = self._pending, []           # p was flagged: it and everything behind it changed nothing
+        self.x3_void.zero_()
+        self.global_step = p['gs0']
+        for n, q in enumerate(pend):
+            self._train_step_now(q['x'], q['spk'], known_flagged=(n == 0))
+
+    def finish_steps(self):
+        """Resolve the deferred steps (defer_guard): afterwards parameters, gradients and losses are those of the last step."""
+        while self._pending:
+            self._resolve_oldest()
+
     def _x3_overflowed(self):
         """Range flag of this step (max over the data-parallel ranks: every rank must take the same branch)."""
         flag = self.x3_flag
@@ -1262,6 +1339,7 @@ class VQVAE:
         """model.encoding of generate.py:92: [B][Cc][Tz] (channel-major).  x [B][T], or ONE utterance [1][T] with
         B speaker ids (generate.py:40 repeats the utterance per speaker: the encoder and VQ then run once and only the
         speaker rows of the condition differ)."""
+        self.finish_steps()
         Bx, T = x.shape
         B = spk.numel()
         if Bx != B and Bx != 1:
@@ -1280,6 +1358,7 @@ class VQVAE:
         self._ws.clear()
 
     def state_dict(self):
+        self.finish_steps()
         # x3_scale: the guarded engine's power-of-two plane scales (measured by the last step, used by the next): with them a
         # resumed run continues exactly as the uninterrupted one would (without them its first step runs on the start-up scales)
         return {'flat': self.flat, 'ema': self.ema, 'adam_m': self.adam_m, 'adam_v': self.adam_v,
@@ -1287,6 +1366,7 @@ class VQVAE:
                 'global_step': torch.tensor(self.global_step, dtype=torch.int64)}
 
     def load_state_dict(self, sd):
+        self.finish_steps()
         for k in ('flat', 'ema', 'adam_m', 'adam_v', 'bn_mean', 'bn_var'):
             getattr(self, k).copy_(sd[k].to(self.dev))
         if 'x3_scale' in sd and tuple(sd['x3_scale'].shape) == tuple(self.x3_scale.shape):      # (absent in round-2 files)
