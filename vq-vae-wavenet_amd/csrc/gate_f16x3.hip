@@ -1081,6 +1081,13 @@ __device__ __forceinline__ WgItem wg_decode(int w, const WgArgs& a) {
     it.prob = rt / cpt;
     it.rtl = rt - it.prob * cpt;
     it.gtile = ((it.prob * a.ntaps + it.tap) * cpt + it.rtl) * a.n_nt + it.nt;
+    // The divisions run on the vector ALU, so the compiler takes everything derived from them for lane-dependent: the problem's
+    // pointers were fetched per lane, the buffer resources built from them lived in VGPRs and every operand request of the main
+    // loop became a readfirstlane "waterfall" loop of its own (26 of them in the planes variant, each a scheduling barrier
+    // between the MFMAs).  One readfirstlane per field states what is true anyway.
+    it.prob = __builtin_amdgcn_readfirstlane(it.prob); it.tap = __builtin_amdgcn_readfirstlane(it.tap);
+    it.rtl = __builtin_amdgcn_readfirstlane(it.rtl); it.nt = __builtin_amdgcn_readfirstlane(it.nt);
+    it.split = __builtin_amdgcn_readfirstlane(it.split); it.gtile = __builtin_amdgcn_readfirstlane(it.gtile);
     return it;
 }
 
