@@ -400,6 +400,13 @@ int vqw_f16x3_gate_conv(const vqw_f16x3_gate_desc* d, vqw_stream_t s);
  * (w: K*ldw floats apart, planes: 2*K*M halves apart) */
 int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, float scale, int count,
                            const float* scale_dev, int mode, vqw_stream_t s);
+/* The same planes of the matrix W'[k][m] that is stored TRANSPOSED, block by block: k = jb * k_inner + ko is
+ * src[jb * blk_stride + m * ld_src + ko] -- e.g. the kernel of a conv's input gradient straight from the forward kernel
+ * w[tap][Cin][Cout] (TF Conv2DBackpropInput: k = (tap, cout), m = cin: k_inner = ld_src = Cout, blk_stride = Cin * Cout), with no
+ * transposed fp32 copy in between.  k_inner % 8 == 0, K % k_inner == 0, rows 16-byte aligned; `count` matrices
+ * (K / k_inner) * blk_stride floats apart.                                                                             */
+int vqw_f16x3_pack_weights_t(const float* w, void* planes, int K, int M, int k_inner, int ld_src, int64_t blk_stride,
+                             float scale, int count, const float* scale_dev, int mode, vqw_stream_t s);
 
 /* The layer's 1x1 skip + residual conv (wavenet_ops.py:132-136, wavenet.py:72-73) on the gated planes:
  * skip[b][m][t] += (W g)[m] + bias[m] for m < S;  net_out[b][c][t] = net_in[b][c][t] + (W g)[S+c] + bias[S+c],

@@ -751,6 +751,30 @@ def test_strided_conv_f16x3_split_k(K, B, Tout, Cin, M, shape, ksplit):
     assert (dx.double() - want_dx.double()).abs().max().item() <= tol * want_dx.abs().max().item()
 
 
+@pytest.mark.parametrize('mode', [0, 1])
+def test_pack_weights_from_transposed_storage(K, mode):
+    """vqw_f16x3_pack_weights_t: the planes of the input-gradient kernels straight from the forward kernels (tap-wise transposed
+    blocks, a row stride wider than the rows used, several matrices per launch) are bit-equal to vqw_f16x3_pack_weights of an
+    explicit transposed copy."""
+    gen = torch.Generator().manual_seed(5)
+    Lc, ks, Cin, Cout = 3, 3, 64, 128
+    w = torch.randn(Lc, ks, Cin, Cout, generator=gen).to(DEV)                      # [layer][tap][cin][cout]
+    sc = torch.tensor([4.0], device=DEV)
+    wt = w.permute(0, 1, 3, 2).contiguous()                                        # [layer][tap][cout][cin]
+    n = Lc * 2 * ks * Cout * Cin
+    want, got = torch.zeros(n, dtype=torch.float16, device=DEV), torch.zeros(n, dtype=torch.float16, device=DEV)
+    K.f16x3_pack_weights(wt, want, ks * Cout, Cin, Cin, 2.0, count=Lc, scale_dev=sc, mode=mode)
+    K.f16x3_pack_weights_t(w, got, ks * Cout, Cin, Cout, Cout, Cin * Cout, 2.0, count=Lc, scale_dev=sc, mode=mode)
+    assert torch.equal(want.view(torch.int16), got.view(torch.int16))
+    # one matrix, only the first 64 of its 128 stored columns (the top layer's skip half: ld_src > k_inner)
+    w2 = torch.randn(Cin, Cout, generator=gen).to(DEV)
+    n2 = 2 * 64 * Cin
+    want2, got2 = torch.zeros(n2, dtype=torch.float16, device=DEV), torch.zeros(n2, dtype=torch.float16, device=DEV)
+    K.f16x3_pack_weights(w2.t().contiguous(), want2, 64, Cin, Cin, 1.0, mode=mode)
+    K.f16x3_pack_weights_t(w2, got2, 64, Cin, 64, Cout, 0, 1.0, mode=mode)
+    assert torch.equal(want2.view(torch.int16), got2.view(torch.int16))
+
+
 @pytest.mark.parametrize('half', [0, 1])
 def test_head_conv_f16x3_epilogue_options(K, half):
     """vqw_f16x3_out_conv epi 2 (the 1x1 convs around the stack and their input gradients): mask * (net_in + W x + bias + upsampled

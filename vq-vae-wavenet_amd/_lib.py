@@ -156,6 +156,7 @@ SIGNATURES = {
     'vqw_f16x3_pack_gate_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _i, _fp]),
     'vqw_f16x3_gate_conv': (_i, [C.POINTER(F16x3GateDesc), _fp]),
     'vqw_f16x3_pack_weights': (_i, [_fp, _fp, _i, _i, _i, _f, _i, _fp, _i, _fp]),
+    'vqw_f16x3_pack_weights_t': (_i, [_fp, _fp, _i, _i, _i, _i, C.c_int64, _f, _i, _fp, _i, _fp]),
     'vqw_f16x3_out_conv': (_i, [C.POINTER(F16x3OutDesc), _fp]),
     'vqw_f16x3_wgrad': (_i, [C.POINTER(F16x3WgradDesc), _fp]),
     'vqw_f16x3_wgrad_batch': (_i, [C.POINTER(F16x3WgradDesc), _i, _fp]),

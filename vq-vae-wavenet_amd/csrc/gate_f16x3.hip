@@ -239,6 +239,30 @@ __global__ void pack_w_kernel(const float* __restrict__ w, uint4* __restrict__ p
     if (!BF) planes[((size_t)KC + kc) * M + m] = p1;
 }
 
+// The same planes from the TRANSPOSED storage: logical row k = jb * Kin + ko, column m is src[jb * blk_stride + m * ld_src + ko]
+// (blocks of Kin rows: the taps of a conv kernel [tap][m][Kin], transposed tap by tap) -- the kernels of the input-gradient GEMMs
+// straight from the parameters, without a transposed fp32 copy in between.  A thread reads its 8 rows as 32 contiguous bytes.
+template <bool BF>
+__global__ void pack_w_t_kernel(const float* __restrict__ w, uint4* __restrict__ planes, int K, int M, int Kin, int ld_src, long blk_stride,
+                                float scale, const float* __restrict__ scale_dev) {
+    scale *= dev_scale(scale_dev);
+    const int KC = K / 8;
+    w += (size_t)blockIdx.y * (K / Kin) * blk_stride;
+    planes += (size_t)blockIdx.y * 2 * KC * M;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KC * M) return;
+    const int m = i % M, kc = i / M, k0 = kc * 8, jb = k0 / Kin, ko = k0 - jb * Kin;
+    const float* src = w + (size_t)jb * blk_stride + (size_t)m * ld_src + ko;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e] * scale; v[4 + e] = b[e] * scale; }
+    uint4 p0, p1;
+    split8<BF>(v, p0, p1);
+    planes[(size_t)kc * M + m] = p0;
+    if (!BF) planes[((size_t)KC + kc) * M + m] = p1;
+}
+
 struct GateArgs {
     vqw_f16x3_gate_desc d;
     int NB;        // B * T rows of the activation planes
@@ -1560,6 +1584,21 @@ int vqw_f16x3_pack_weights(const float* w, void* planes, int K, int M, int ldw, 
     if (mode & 1) hipLaunchKernelGGL(pack_w_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
     else hipLaunchKernelGGL(pack_w_kernel<false>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, ldw, scale, scale_dev);
     VQW_LAUNCH_CHECK("vqw_f16x3_pack_weights");
+    return 0;
+}
+
+int vqw_f16x3_pack_weights_t(const float* w, void* planes, int K, int M, int k_inner, int ld_src, int64_t blk_stride, float scale, int count,
+                             const float* scale_dev, int mode, vqw_stream_t s_) {
+    hipStream_t st = (hipStream_t)s_;
+    VQW_CHECK(w && planes, "vqw_f16x3_pack_weights_t: null pointer");
+    VQW_CHECK(K > 0 && M > 0 && k_inner > 0 && k_inner % 8 == 0 && K % k_inner == 0 && ld_src >= k_inner && ld_src % 4 == 0 && blk_stride % 4 == 0 &&
+              blk_stride >= 0 && count >= 1 && count <= 65535 && (reinterpret_cast<uintptr_t>(w) & 15) == 0,
+              "vqw_f16x3_pack_weights_t: needs k_inner %% 8 == 0, K %% k_inner == 0, ld_src >= k_inner, 16-byte aligned rows (K=%d M=%d k_inner=%d ld_src=%d)",
+              K, M, k_inner, ld_src);
+    const int n = (K / 8) * M;
+    if (mode & 1) hipLaunchKernelGGL(pack_w_t_kernel<true>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, k_inner, ld_src, (long)blk_stride, scale, scale_dev);
+    else hipLaunchKernelGGL(pack_w_t_kernel<false>, dim3((n + 255) / 256, count), dim3(256), 0, st, w, (uint4*)planes, K, M, k_inner, ld_src, (long)blk_stride, scale, scale_dev);
+    VQW_LAUNCH_CHECK("vqw_f16x3_pack_weights_t");
     return 0;
 }
 

@@ -289,6 +289,17 @@ def f16x3_pack_weights(w, planes, Kd, M, ldw, scale, count=1, scale_dev=None, mo
     L.check(L.lib().vqw_f16x3_pack_weights(L.ptr(w), L.ptr(planes), Kd, M, ldw, float(scale), count, _slot(scale_dev, 'scale_dev'), mode, L.stream()))
 
 
+def f16x3_pack_weights_t(w, planes, Kd, M, k_inner, ld_src, blk_stride, scale, count=1, scale_dev=None, mode=None):
+    """Planes of the matrix W'[k][m] = w[(k // k_inner) * blk_stride + m * ld_src + k % k_inner]: the kernel of an input-gradient GEMM
+    straight from the forward kernel (no transposed fp32 copy); `count` matrices (Kd // k_inner) * blk_stride floats apart."""
+    mode = x3_mode(mode)
+    nblk = Kd // k_inner
+    _need(w, (count - 1) * nblk * blk_stride + (nblk - 1) * blk_stride + (M - 1) * ld_src + k_inner, 'w')
+    _need_planes(planes, count * 2 * Kd * M, 'planes')
+    L.check(L.lib().vqw_f16x3_pack_weights_t(L.ptr(w), L.ptr(planes), Kd, M, k_inner, ld_src, blk_stride, float(scale), count,
+                                             _slot(scale_dev, 'scale_dev'), mode, L.stream()))
+
+
 def f16x3_out_conv(*, xp, wp, B, T, R, S, w_scale_inv, skip=None, net_in=None, net_out=None, bias=None,
                    net_out_planes=None, Cin=0, xp_kc0=0, xp_KC=0, ks=1, dilation=1, direction=1,
                    planes_kc0=0, planes_KC=0, plane_scale=0.0, epi=0, aux0=None, aux1=None, x_scale=None, w_scale=None,

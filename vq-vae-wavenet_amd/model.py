@@ -794,19 +794,17 @@ class VQVAE:
         return out
 
     # ------------------------------------------------------------------ backward
-    def _transpose_weights(self):
-        P, Tt, L, ks, R, S, F = self.P, self.T, self.L, self.ks, self.R, self.S, self.F
-        K.transpose(P['gated_w'], Tt['gated_w'], L * ks, R, 2 * R)
-        K.transpose(P['out_w'], Tt['out_w'], L, R, S + R)
-        K.transpose(P['post1_w'], Tt['post1_w'], 1, S, S)
-        K.transpose(P['post2_w'], Tt['post2_w'], 1, S, self.Q)
-        K.transpose(P['skip0_w'], Tt['skip0_w'], 1, R, S)
-        K.transpose(P['cond_w'], Tt['cond_w'], 1, self.Cc, self.Mall)
-        if self.enc == '64':
-            K.transpose(P['enc_w'], Tt['enc_w'], 25, F, F)
-            K.transpose(P['enc_w6'], Tt['enc_w6'], 1, F, self.D)
-        else:
-            self.magenta.transpose(P, Tt)
+    def _tt(self, name):
+        """The transposed fp32 copy of a kernel for the fp32 engine's input-gradient GEMMs, made on first use in this backward pass
+        (the fp16x3 engine packs its planes straight from the parameters, vqw_f16x3_pack_weights_t: on the default path only the
+        condition projection and the encoder's last 1x1 layer still need a copy -- six transposes per step fewer)."""
+        if name not in self._tt_done:
+            L, ks, R, S, F = self.L, self.ks, self.R, self.S, self.F
+            shape = {'gated_w': (L * ks, R, 2 * R), 'out_w': (L, R, S + R), 'post1_w': (1, S, S), 'post2_w': (1, S, self.Q),
+                     'skip0_w': (1, R, S), 'cond_w': (1, self.Cc, self.Mall), 'enc_w': (25, F, F), 'enc_w6': (1, F, self.D)}[name]
+            K.transpose(self.P[name], self.T[name], *shape)
+            self._tt_done.add(name)
+        return self.T[name]
 
     def backward(self, x, spk, ws):
         """Gradients of loss = CE + vq + commitment (model.py:90-106) w.r.t. every trainable
@@ -815,7 +813,9 @@ class VQVAE:
         R, S, Q, L, F, D, ks = self.R, self.S, self.Q, self.L, self.F, self.D, self.ks
         B, T, Tz, ratio = ws['B'], ws['T'], ws['Tz'], ws['ratio']
         self.grad.zero_()
-        self._transpose_weights()
+        self._tt_done = set()
+        if self.enc != '64':
+            self.magenta.transpose(P, Tt)
         dlog, h1, skip = ws['logits'], ws['h1'], ws['skip']
         cbs = self.Mall * Tz
         dce = ws['dcondenc']
@@ -829,9 +829,9 @@ class VQVAE:
             ham = (lambda name: self.x3_amax[self.SL[name]:self.SL[name] + 1]) if self.x3_guard else (lambda name: None)       # noqa: E731
             mdh, dl, hflag = self.x3_mode_bwd, ws['dl_scale'], (self.x3_flag if self.x3_guard else None)
             self._wslab(ws)
-            K.f16x3_pack_weights(Tt['post2_w'], ws['wpost2t'], Q, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
-            K.f16x3_pack_weights(Tt['post1_w'], ws['wpost1t'], S, S, S, 1.0, scale_dev=hsc('WH'), mode=mdh)
-            K.f16x3_pack_weights(Tt['skip0_w'], ws['wskip0t'], S, R, R, 1.0, scale_dev=hsc('WH'), mode=mdh)
+            K.f16x3_pack_weights_t(P['post2_w'], ws['wpost2t'], Q, S, Q, Q, 0, 1.0, scale_dev=hsc('WH'), mode=mdh)
+            K.f16x3_pack_weights_t(P['post1_w'], ws['wpost1t'], S, S, S, S, 0, 1.0, scale_dev=hsc('WH'), mode=mdh)
+            K.f16x3_pack_weights_t(P['skip0_w'], ws['wskip0t'], S, R, S, S, 0, 1.0, scale_dev=hsc('WH'), mode=mdh)
             dce.zero_()
             # ---- postprocess2 (wavenet.py:93-96)
             K.f16x3_split_activations(dlog, ws['hp2'], B, Q, T, scale_dev=dl, mode=mdh)
@@ -851,7 +851,7 @@ class VQVAE:
             # ---- postprocess2 (wavenet.py:93-96)
             K.wgrad_gemm(p=h1, p_relu=True, q0=dlog, dw=G['post2_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=Q, taps=[0])
             K.rowsum(dlog, total=G['post2_b'])
-            K.conv_gemm(x0=dlog, w=Tt['post2_w'], out0=h1, aux0=h1, B=B, T_in=T, T_out=T, M=S, C0=Q, taps=[0],
+            K.conv_gemm(x0=dlog, w=self._tt('post2_w'), out0=h1, aux0=h1, B=B, T_in=T, T_out=T, M=S, C0=Q, taps=[0],
                         epilogue=K.EPI_MASK)                       # h1 := d h1 (pre-relu)
             if self.x3_guard and not self._x3_active:              # fp32 repeat of a step: what the planes would have held
                 K.f16x3_amax(h1, self.x3_amax[self.SL['DH']:self.SL['DH'] + 1])
@@ -860,7 +860,7 @@ class VQVAE:
             seg_p1 = A.empty(B, S, Tz, device=self.dev)
             K.rowsum(h1, seg_out=seg_p1, total=G['post1_b'], seg=ratio)
             dce[:, L * 2 * R:].copy_(seg_p1)
-            K.conv_gemm(x0=h1, w=Tt['post1_w'], out0=skip, aux0=skip, B=B, T_in=T, T_out=T, M=S, C0=S, taps=[0],
+            K.conv_gemm(x0=h1, w=self._tt('post1_w'), out0=skip, aux0=skip, B=B, T_in=T, T_out=T, M=S, C0=S, taps=[0],
                         epilogue=K.EPI_MASK)                       # skip := d skip (same for every layer)
         dskip = skip
         # ---- residual stack, top layer first (wavenet.py:63-74)
@@ -896,10 +896,10 @@ class VQVAE:
         if wg_x3:
             self._wslab(ws)
         if dgrad_x3:
-            K.f16x3_pack_weights(Tt['gated_w'], ws['wdg'], ks * 2 * R, R, R, WS, count=L, scale_dev=sc('WG'), mode=md)
+            K.f16x3_pack_weights_t(P['gated_w'], ws['wdg'], ks * 2 * R, R, 2 * R, 2 * R, R * 2 * R, WS, count=L, scale_dev=sc('WG'), mode=md)
         if gbwd_x3:
-            K.f16x3_pack_weights(Tt['out_w'], ws['wgb'], S + R, R, R, WS, count=L, scale_dev=sc('WO'), mode=md)
-            K.f16x3_pack_weights(Tt['out_w'][L - 1], ws['wgb_top'], S, R, R, WS, scale_dev=sc('WO'), mode=md)       # the top layer has no dnet
+            K.f16x3_pack_weights_t(P['out_w'], ws['wgb'], S + R, R, S + R, S + R, R * (S + R), WS, count=L, scale_dev=sc('WO'), mode=md)
+            K.f16x3_pack_weights_t(P['out_w'][L - 1], ws['wgb_top'], S, R, S, S + R, 0, WS, scale_dev=sc('WO'), mode=md)       # the top layer has no dnet
             if not head_x3:      # (the input gradient of postprocess1 wrote them otherwise)
                 K.f16x3_split_activations(dskip, ws['gr'], B, S, T, scale=GS, kc0=0, KC=(S + R) // 8, scale_dev=sc('G'),
                                           amax=am('G'), flag=flag, mode=md)   # one tensor for all layers
@@ -993,7 +993,7 @@ class VQVAE:
                                  net_out_planes=dplanes, plane_scale=GS, B=B, T=T, R=R, S=0, w_scale_inv=1.0 / (WS * GS),
                                  x_scale=sc('G'), w_scale=sc('WO'), out_scale=sc('DP', l), out_amax=am('DP', l), flag=flag, mode=md)
             else:
-                K.conv_gemm(x0=dskip, x1=None if top else dnet, w=Tt['out_w'][l], out0=dpre, aux0=ws['th'][l],
+                K.conv_gemm(x0=dskip, x1=None if top else dnet, w=self._tt('out_w')[l], out0=dpre, aux0=ws['th'][l],
                             aux1=ws['sg'][l], B=B, T_in=T, T_out=T, M=R, C0=S, C1=0 if top else R, taps=[0],
                             epilogue=K.EPI_GATE_BWD, tile=self.tiles['gate_bwd'])
             if calib:
@@ -1012,10 +1012,10 @@ class VQVAE:
                                  planes_KC=(S + R) // 8 if gbwd_x3 else 0, plane_scale=GS if gbwd_x3 else 0.0,
                                  x_scale=sc('DP', l), w_scale=sc('WG'), out_scale=sc('G'), out_amax=am('G'), flag=flag, mode=self.x3_mode_dgrad)
             elif top:
-                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
+                K.conv_gemm(x0=dpre, w=self._tt('gated_w')[l], out0=dnet_next, B=B, T_in=T, T_out=T, M=R, C0=2 * R, taps=taps_b,
                             tile=self.tiles['dgrad'])
             else:
-                K.conv_gemm(x0=dpre, w=Tt['gated_w'][l], out1=dnet_next, aux1=dnet, out0=dnet_next, B=B, T_in=T, T_out=T,
+                K.conv_gemm(x0=dpre, w=self._tt('gated_w')[l], out1=dnet_next, aux1=dnet, out0=dnet_next, B=B, T_in=T, T_out=T,
                             M=R, M0=0, C0=2 * R, taps=taps_b, epilogue=K.EPI_ACCUM_SPLIT, tile=self.tiles['dgrad'])
             if calib:
                 K.f16x3_amax(dnet_next, am('G'))
@@ -1069,7 +1069,7 @@ class VQVAE:
             K.f16x3_out_conv(xp=ws['gr'], xp_KC=(S + R) // 8, Cin=S, wp=ws['wskip0t'], net_in=dnet, net_out=dnet, B=B, T=T, R=R, S=0,
                              w_scale_inv=1.0 / GS, x_scale=sc('G'), w_scale=sc('WH'), mode=md)
         else:
-            K.conv_gemm(x0=dskip, w=Tt['skip0_w'], out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
+            K.conv_gemm(x0=dskip, w=self._tt('skip0_w'), out1=dnet, aux1=dnet, out0=dnet, B=B, T_in=T, T_out=T, M=R, M0=0,
                         C0=S, taps=[0], epilogue=K.EPI_ACCUM_SPLIT)
         ws['bskip'].zero_()      # sum of dskip over batch and time: the bias gradient of skip0 and of every layer's skip half
         if wg_x3:      # both operands already have guard scales (layer-0 input planes, gradient planes); the sum rides along
@@ -1084,7 +1084,7 @@ class VQVAE:
         K.rowsum(dnet, total=G['pre_b'])
         # ---- local condition (wavenet_ops.py:93-101) -> d cond
         K.wgrad_gemm(p=ws['cond'], q0=dce, dw=G['cond_w'], B=B, T_q=Tz, T_p=Tz, Cp=self.Cc, Q0=self.Mall, taps=[0])
-        K.conv_gemm(x0=dce, w=Tt['cond_w'], out0=ws['dcond'], B=B, T_in=Tz, T_out=Tz, M=self.Cc, C0=self.Mall, taps=[0])
+        K.conv_gemm(x0=dce, w=self._tt('cond_w'), out0=ws['dcond'], B=B, T_in=Tz, T_out=Tz, M=self.Cc, C0=self.Mall, taps=[0])
         if self.grad_sync is not None:      # decoder gradients are final: exchange them under the encoder backward
             self.grad_sync.bucket_ready(self.seg_off['pre_w'][0], self.n_flat)
         # ---- speaker embedding + VQ (model.py:22-27, 57-74, 99-106)
@@ -1109,7 +1109,7 @@ class VQVAE:
         K.bn_relu_bwd_sums(dz, ws['y6'], None, sc[6 * F:], dz, dscale=dsc[6 * F:], dbeta=G['bn_beta'][6 * F:],
                            dbias=G['enc_b6'])                        # dz := d(conv6 output)
         K.wgrad_gemm(p=ws['X'][5], q0=dz, dw=G['enc_w6'], B=B, T_q=Tz, T_p=Tz, Cp=F, Q0=D, taps=[0])
-        K.conv_gemm(x0=dz, w=Tt['enc_w6'], out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
+        K.conv_gemm(x0=dz, w=self._tt('enc_w6'), out0=ws['dX'][5], B=B, T_in=Tz, T_out=Tz, M=F, C0=D, taps=[0])
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else main
         # layers 1..5 on the fp16x3 engine: the input gradient where the forward conv ran there (ws['enc_x3']), the weight
@@ -1120,7 +1120,7 @@ class VQVAE:
                and os.environ.get('VQW_ENC_WGRAD_X3', '1') != '0')
         ea, es, flag = ws.get('enc_amax'), ws.get('enc_scale'), self.x3_flag
         if ex3:
-            K.f16x3_pack_weights(Tt['enc_w'], ws['ewtp'], 5 * F, F, F, 1.0, count=5, scale_dev=es[0:1], mode=0)
+            K.f16x3_pack_weights_t(P['enc_w'], ws['ewtp'], 5 * F, F, F, F, F * F, 1.0, count=5, scale_dev=es[0:1], mode=0)
         for i in range(5, -1, -1):
             dX, r = ws['dX'][i], ws['r'][i]
             Ti = ws['Tl'][i]
@@ -1184,7 +1184,7 @@ class VQVAE:
             for p in (0, 1):
                 j0 = (p + pl) % 2
                 js = list(range(j0, 5, 2))
-                K.conv_gemm(x0=dX, w=Tt['enc_w'][i - 1][j0:], w_tap_stride=2 * F * F, out0=ws['dX'][i - 1], B=B,
+                K.conv_gemm(x0=dX, w=self._tt('enc_w')[i - 1][j0:], w_tap_stride=2 * F * F, out0=ws['dX'][i - 1], B=B,
                             T_in=Ti, T_out=(Tin - p + 1) // 2, M=F, C0=F, taps=[(p + pl - j) // 2 for j in js],
                             out_tstride=2, out_toffset=p, T_store=Tin, tile=12 if nsplit > 1 else 0,
                             split_k=-nsplit if nsplit > 1 else 0)
