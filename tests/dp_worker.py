@@ -54,8 +54,8 @@ def guard_problem():
     return m, w, P, x, spk
 
 
-def rccl_one_rank(pkg, out_dir):
-    """See the module docstring: mode rccl1."""
+def rccl_one_rank(pkg, out_dir, deferred=False):
+    """See the module docstring: mode rccl1 (rccl1_deferred: model.defer_guard, the flag all-reduce stays on the device)."""
     dev = torch.device('cuda', 0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     m, w, P, x, spk = guard_problem()
@@ -63,6 +63,7 @@ def rccl_one_rank(pkg, out_dir):
     model = pkg.model.VQVAE(m, w, 10, device='cuda', seed=0)
     model.load_named(P)
     sync = model.grad_sync = pkg.parallel.GradAllReduce(model.grad, force=True)
+    model.defer_guard = deferred
     assert sync.active and sync.world == 1
     seen = {'buckets': [], 'identical': True, 'max_calls': 0}
     real_all_reduce = dist.all_reduce
@@ -79,6 +80,9 @@ def rccl_one_rank(pkg, out_dir):
     dist.all_reduce = checked_all_reduce
     try:
         ws = model.train_step(x, spk)
+        if deferred:
+            assert len(model._pending) == 1 and model.x3_fallbacks == 0
+            model.finish_steps()
     finally:
         dist.all_reduce = real_all_reduce
     torch.cuda.synchronize()
@@ -101,8 +105,8 @@ def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     pkg = importlib.import_module('vq-vae-wavenet_amd')
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
-    if mode == 'rccl1':
-        return rccl_one_rank(pkg, out_dir)
+    if mode in ('rccl1', 'rccl1_deferred'):
+        return rccl_one_rank(pkg, out_dir, deferred=(mode == 'rccl1_deferred'))
     dist.init_process_group(backend, rank=rank, world_size=world)
     m, w, P, x, spk = guard_problem() if mode.startswith('guard') else shared_problem()
     model = pkg.model.VQVAE(m, w, 10, device='cuda', seed=0)

@@ -110,14 +110,16 @@ def test_deferred_range_flag_under_data_parallelism(pkg, tmp_path):
     assert float((r0['flat'] - full.flat.cpu())[big].abs().max()) < 1e-5
 
 
-def test_one_rank_on_rccl_runs_the_bucketed_exchange(pkg, tmp_path):
+@pytest.mark.parametrize('mode', ['rccl1', 'rccl1_deferred'])
+def test_one_rank_on_rccl_runs_the_bucketed_exchange(pkg, tmp_path, mode):
     """RCCL itself, on the one GPU this box has: a fresh child with WORLD_SIZE=1, backend nccl, GradAllReduce(force=True).
     The decoder bucket, the per-layer encoder buckets and the rest are all-reduced on the side stream by the real
     communicator and the flag MAX-all-reduce runs on it too (the step is flagged and repeated: every bucket goes twice).
     A 1-rank sum is the identity: every bucket comes back bit-identical, the buckets tile [0, n_flat) exactly once per
     pass, and the step equals the same step without a grad_sync (not bitwise: the fp32 engine's split-K atomics make two
-    evaluations differ in the last bits)."""
-    run_ranks([os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path), 'nccl', 'rccl1'], 1)
+    evaluations differ in the last bits).  rccl1_deferred: the same with model.defer_guard -- the flag's MAX all-reduce is enqueued
+    on the device in front of the guarded optimiser and the host learns of the flagged step in finish_steps()."""
+    run_ranks([os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path), 'nccl', mode], 1)
     r = torch.load(str(tmp_path / 'rccl1.pt'), weights_only=True)
     assert bytes(r['backend'].tolist()).decode() == 'nccl'
     assert bool(r['identical']), 'a bucket changed under a 1-rank all-reduce'
