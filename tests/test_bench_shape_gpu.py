@@ -62,9 +62,12 @@ def _oracle_step(pkg):
     return _ORACLE
 
 
-@pytest.mark.parametrize('engine', ['f16x3', 'fp32'])
+@pytest.mark.parametrize('engine', ['f16x3', 'f16x3_deferred', 'fp32'])
 def test_bench_workload_full_step_matches_oracle(pkg, monkeypatch, engine):
-    """engine: the default (fp16x3 with range guards: what bench.py times) and the fp32-MFMA engine (VQW_ENGINE=fp32)."""
+    """engine: the default (fp16x3 with range guards: what bench.py times), the same with the range flag read one step late
+    (model.defer_guard, as bench.py and train.py run it) and the fp32-MFMA engine (VQW_ENGINE=fp32)."""
+    deferred = engine.endswith('_deferred')
+    engine = engine.replace('_deferred', '')
     monkeypatch.setenv('VQW_ENGINE', engine)
     o = _oracle_step(pkg)
     m, w, x, spk, P, grads, out = o['m'], o['w'], o['x'], o['spk'], o['P'], o['grads'], o['out']
@@ -78,7 +81,12 @@ def test_bench_workload_full_step_matches_oracle(pkg, monkeypatch, engine):
     logits = ws['logits'].permute(0, 2, 1).reshape(-1, model.Q)
     assert relerr(logits, out['logits']) < 5e-4
     del logits
+    model.defer_guard = deferred
     ws = model.train_step(x, spk)
+    if deferred:
+        assert len(model._pending) == 1            # enqueued behind the device-side guard, not yet looked at by the host
+        model.finish_steps()
+        assert model.x3_steps == 1 and int(model.x3_void.item()) == 0
     assert bool(ws['x3_used']) == (engine == 'f16x3') and model.x3_fallbacks == 0
     loss, recon, vq, commit = model.losses(ws)
     np.testing.assert_allclose(recon, out['reconstruction_loss'].item(), rtol=2e-5)

@@ -663,6 +663,8 @@ class VQVAE:
                                   out_planes_kc0=l * (R // 8) if f16x3_skip else 0, out_planes_KC=L * (R // 8) if f16x3_skip else 0,
                                   x_scale=sc('X', l), w_scale=sc('WG'), mode=md)
                 if f16x3_skip:   # residual half now; the skip half of all layers after the loop
+                    if l == L - 1:
+                        continue     # the top layer's residual output feeds nothing (wavenet.py:58-78: TF prunes the op from the graph)
                     K.f16x3_out_conv(xp=ws['gp'], xp_kc0=l * (R // 8), xp_KC=L * (R // 8), Cin=R, wp=ws['wres'][l],
                                      bias=P['out_b'][l][S:], net_in=net[l], net_out=net[l + 1], net_out_planes=xpl(l + 1),
                                      B=B, T=T, R=R, S=0, w_scale_inv=1.0 / WS, w_scale=sc('WO'), out_scale=sc('X', l + 1),
@@ -1250,7 +1252,7 @@ class VQVAE:
                 try:
                     self.x3_amax.zero_()
                     ws = self.forward(x, spk)
-                    for l in range(1, self.L + 1):   # what the layer-input planes would have held
+                    for l in range(1, self.L):       # what the layer-input planes would have held (net[L] feeds nothing)
                         K.f16x3_amax(ws['net'][l], self.x3_amax[self.SL['X'] + l:self.SL['X'] + l + 1])
                     K.f16x3_amax(ws['skip'], self.x3_amax[self.SL['SK']:self.SL['SK'] + 1])
                     K.f16x3_amax(ws['h1'], self.x3_amax[self.SL['H1']:self.SL['H1'] + 1])
