@@ -356,6 +356,11 @@ def test_deferred_guard_matches_immediate(pkg, monkeypatch):
         ta_, tb_ = getattr(a, name), getattr(b, name)
         assert torch.isfinite(tb_).all(), name
         assert l2err(tb_, ta_) < bar, '%s: deferred vs immediate rel. L2 %.3e' % (name, l2err(tb_, ta_))
+    # a caller's own forward pass (evaluation between training steps) settles the pending step first
+    b.train_step(*batches[0])
+    assert len(b._pending) == 1
+    b.forward(*batches[1], compute_grad_seed=False)
+    assert not b._pending and b.global_step == 7
 
 
 @pytest.mark.parametrize('B,T', [(1, 1280), (2, 6400)])

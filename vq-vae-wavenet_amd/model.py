@@ -153,7 +153,7 @@ class VQVAE:
         self.x3_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.x3_void = torch.zeros(1, dtype=torch.int32, device=self.dev)      # deferred mode: a flagged step is waiting to be repeated
         self.defer_guard = os.environ.get('VQW_DEFER_GUARD', '0') == '1'       # read the range flag one step late (train_step)
-        self._pending, self._void_host, self._void_slot = [], None, 0
+        self._pending, self._void_host, self._void_slot, self._in_step = [], None, 0, False
         self.host_enqueue_ms = None
 
     # ------------------------------------------------------------------ parameter layout
@@ -715,6 +715,8 @@ class VQVAE:
         """model.py:145-151 up to the losses.  x [B][T] raw audio in [-1,1], spk int64 [B].
         Leaves logits (or d loss/d logits when compute_grad_seed) in the workspace and the
         loss sums in self.loss_buf (no host sync)."""
+        if self._pending and not self._in_step:      # a caller's own forward pass between deferred steps: settle those first
+            self.finish_steps()
         B, T = x.shape
         ws = self._workspace(B, T)
         if A.POISON:             # debug: every workspace buffer and the transposed-kernel scratch start the step as NaN
@@ -1284,8 +1286,12 @@ class VQVAE:
         finish_steps() before reading what a step left behind (losses, gradients, parameters; state_dict() / encode() do)."""
         t_host = time.perf_counter()
         self.x3_flag.zero_()
-        ws = self.forward(x, spk)
-        self.backward(x, spk, ws)
+        self._in_step = True
+        try:
+            ws = self.forward(x, spk)
+            self.backward(x, spk, ws)
+        finally:
+            self._in_step = False
         world = self.grad_sync.finish() if self.grad_sync is not None else 1
         if not (ws.get('x3_used') or ws.get('enc_x3')):       # nothing on the guarded engine in this workspace
             self.apply_gradients(1.0 / world)
