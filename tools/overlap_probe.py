@@ -84,3 +84,47 @@ for name, fn in (('gate conv', gate), ('gate backward', gbwd), ('input gradient'
     torch.cuda.synchronize()
     two = max(start.elapsed_time(end1), start.elapsed_time(end2)) / (2 * n) * 1e3
     print('%-16s one stream %6.1f us per launch   two streams %6.1f us per launch   (%.0f %%)' % (name, one, two, 100 * two / one), flush=True)
+
+
+# Mixed pairs: the backward main chain (gate backward + input gradient, n layers) on one stream with an independent MFMA-heavy
+# 256-register kernel (the 128-row gate conv: a stand-in for a register-light weight-gradient kernel) on the other, against the
+# same launches back to back on one stream.
+def dgrad_half(b):
+    K.f16x3_out_conv(xp=dp, Cin=2 * R, ks=ks, dilation=8, direction=-1, wp=wdg, net_in=dnet, net_out=b['dn'], B=B, T=T, R=R, S=0,
+                     w_scale_inv=2.0 ** -28, net_out_planes=b['grp'], planes_kc0=S // 8, planes_KC=(S + R) // 8, plane_scale=2.0 ** 20, mode=HB)
+
+
+def timed(fn_main, fn_side, two):
+    torch.cuda.synchronize()
+    start, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    start.record()
+    if two:
+        s1.wait_event(start); s2.wait_event(start)
+        with torch.cuda.stream(s1):
+            fn_main()
+            e1.record()
+        with torch.cuda.stream(s2):
+            fn_side()
+            e2.record()
+        torch.cuda.synchronize()
+        return max(start.elapsed_time(e1), start.elapsed_time(e2)) * 1e3
+    fn_main(); fn_side()
+    e1.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(e1) * 1e3
+
+
+for name, dg in (('input gradient 256-row blocks', dgrad), ('input gradient 128-row blocks', dgrad_half)):
+    def chain():
+        for _ in range(n):
+            gbwd(A); dg(A)
+    for m in (n, 2 * n):
+        def side():
+            for _ in range(m):
+                gate(Bb)
+        timed(chain, side, False)
+        seq = timed(chain, side, False)
+        timed(chain, side, True)
+        par = timed(chain, side, True)
+        print('%d x (gate backward + %s) with %d gate convs beside them: one stream %7.1f us   two streams %7.1f us   (%.0f %%)' % (
+            n, name, m, seq, par, 100 * par / seq), flush=True)
