@@ -313,13 +313,16 @@ class VQVAE:
     def named_parameters(self, ema=False):
         """Copies of all variables under the reference's names (ema=True: the EMA shadows
         that generate.py:88-90 restores)."""
+        self.finish_steps()
         return OrderedDict((k, v.detach().clone()) for k, v in self._named(self.E if ema else self.P).items())
 
     def named_gradients(self):
+        self.finish_steps()
         return OrderedDict((k, v.detach().clone()) for k, v in self._named(self.G, bn_stats=False).items())
 
     def load_named(self, params, also_ema=True):
         """Load variables given under the reference's names (any device)."""
+        self.finish_steps()
         dst = self._named(self.P)
         for name, view in dst.items():
             if name not in params:
