@@ -245,6 +245,23 @@ int vqw_softmax_xent_bwd(const float* logits, const int32_t* labels, float* dlog
                          int B, int Q, int T, vqw_stream_t s);
 
 /* ------------------------------------------------------------------------------------
+ * The decoder's local-condition projections -- add_condition, wavenet_ops.py:93-101: a 1x1 conv1d_v2 of the condition
+ * per gated_cnn and for postprocess1 (wavenet.py:58-100).  All L + 1 kernels side by side are one matrix
+ * w[Cc][Mall] (Mall = L * 2R + S); cond [B][Cc][Tz], out / dce [B][Mall][Tz], dcond [B][Cc][Tz].
+ *   fwd:    out[b][m][t]   = sum_c w[c][m] cond[b][c][t]
+ *   wgrad:  dw[c][m]      += sum_{b,t} cond[b][c][t] dce[b][m][t]     (TF Conv2DBackpropFilter); Cc <= 128, Tz % 4 == 0;
+ *           dw is the zeroed gradient buffer (two batch ranges may meet in it by fp32 atomics)
+ *   dgrad:  dcond[b][c][t] = sum_m w[c][m] dce[b][m][t]               (TF Conv2DBackpropInput); Cc <= 128, Mall % 4 == 0;
+ *           scratch: vqw_cond_proj_dgrad_scratch_floats() floats (partial sums over ranges of m, added in a fixed order)
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32) fed straight from global memory, one tile per wave: a contraction of Cc ~ 80 over
+ * 104-frame rows is too short for the conv engine's K loops and 128-column tiles.                                   */
+int vqw_cond_proj_fwd(const float* cond, const float* w, float* out, int B, int Cc, int Mall, int Tz, vqw_stream_t s);
+int vqw_cond_proj_wgrad(const float* cond, const float* dce, float* dw, int B, int Cc, int Mall, int Tz, vqw_stream_t s);
+int vqw_cond_proj_dgrad(const float* w, const float* dce, float* dcond, float* scratch, int64_t scratch_floats,
+                        int B, int Cc, int Mall, int Tz, vqw_stream_t s);
+int vqw_cond_proj_dgrad_scratch_floats(int B, int Cc, int Mall, int Tz, int64_t* out);
+
+/* ------------------------------------------------------------------------------------
  * Fused TF-1.x Adam + ExponentialMovingAverage step over a flat buffer --
  * model.py:116-128:
  *   g = grad*grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;

@@ -751,6 +751,38 @@ def test_strided_conv_f16x3_split_k(K, B, Tout, Cin, M, shape, ksplit):
     assert (dx.double() - want_dx.double()).abs().max().item() <= tol * want_dx.abs().max().item()
 
 
+@pytest.mark.parametrize('B,Cc,Mall,Tz', [(8, 80, 15872, 104), (3, 24, 1000, 12), (2, 128, 320, 132), (1, 1, 64, 4), (5, 33, 36, 200)])
+def test_condition_projection_kernels(K, B, Cc, Mall, Tz):
+    """vqw_cond_proj_fwd / _wgrad / _dgrad (add_condition's 1x1 conv of every layer in one matrix, wavenet_ops.py:93-101) against
+    fp64: the benchmark's shape, channel counts that are not multiples of the 32-row MFMA tiles, frame rows shorter and longer than
+    the 128-frame pass, an odd batch (the weight gradient's two batch ranges are unequal), the smallest shape.  Exact fp32 products
+    (v_mfma_f32_32x32x2_f32): the bars are those of an fp32 sum of that length.  Forward and input gradient are reproducible bit for
+    bit; the weight gradient accumulates into dw."""
+    gen = torch.Generator().manual_seed(Cc * 7 + Tz)
+    cond = torch.randn(B, Cc, Tz, generator=gen).to(DEV)
+    w = (torch.randn(Cc, Mall, generator=gen) * 0.3).to(DEV)
+    dce = torch.randn(B, Mall, Tz, generator=gen).to(DEV)
+    out = torch.full((B, Mall, Tz), float('nan'), device=DEV)
+    K.cond_proj_fwd(cond, w, out, B=B, Cc=Cc, Mall=Mall, Tz=Tz)
+    want = torch.einsum('cm,bct->bmt', w.double(), cond.double())
+    assert (out.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    dw = torch.zeros(Cc, Mall, device=DEV)
+    K.cond_proj_wgrad(cond, dce, dw, B=B, Cc=Cc, Mall=Mall, Tz=Tz)
+    want_dw = torch.einsum('bct,bmt->cm', cond.double(), dce.double())
+    assert (dw.double() - want_dw).abs().max().item() <= 3e-6 * want_dw.abs().max().item()
+    K.cond_proj_wgrad(cond, dce, dw, B=B, Cc=Cc, Mall=Mall, Tz=Tz)           # accumulates
+    assert (dw.double() - 2 * want_dw).abs().max().item() <= 6e-6 * want_dw.abs().max().item()
+    scratch = torch.full((K.cond_proj_dgrad_scratch(B, Cc, Mall, Tz),), float('nan'), device=DEV)
+    dcond = torch.full((B, Cc, Tz), float('nan'), device=DEV)
+    K.cond_proj_dgrad(w, dce, dcond, scratch, B=B, Cc=Cc, Mall=Mall, Tz=Tz)
+    want_dc = torch.einsum('cm,bmt->bct', w.double(), dce.double())
+    assert (dcond.double() - want_dc).abs().max().item() <= 1e-5 * want_dc.abs().max().item()
+    out2, dcond2 = torch.empty_like(out), torch.empty_like(dcond)
+    K.cond_proj_fwd(cond, w, out2, B=B, Cc=Cc, Mall=Mall, Tz=Tz)
+    K.cond_proj_dgrad(w, dce, dcond2, scratch, B=B, Cc=Cc, Mall=Mall, Tz=Tz)
+    assert torch.equal(out, out2) and torch.equal(dcond, dcond2)
+
+
 @pytest.mark.parametrize('mode', [0, 1])
 def test_pack_weights_from_transposed_storage(K, mode):
     """vqw_f16x3_pack_weights_t: the planes of the input-gradient kernels straight from the forward kernels (tap-wise transposed

@@ -42,3 +42,12 @@ for sk in (0, 2, 4, 8):
     except Exception as e:
         print('split_k', sk, type(e).__name__, e)
 print('weight gradient %6.1f us' % timeit(lambda: K.wgrad_gemm(p=cond, q0=dce, dw=dw, B=B, T_q=Tz, T_p=Tz, Cp=Cc, Q0=M, taps=[0])))
+# the dedicated fp32-MFMA kernels (csrc/cond_proj.hip: one tile per wave, operands straight from global memory)
+for cc in (80, 128):
+    c2, w2 = cond[:, :cc].contiguous(), w[:cc].contiguous()
+    dc2, dw2 = torch.empty(B, cc, Tz, device=dev), torch.zeros(cc, M, device=dev)
+    scratch = torch.empty(K.cond_proj_dgrad_scratch(B, cc, M, Tz), device=dev)
+    f = timeit(lambda: K.cond_proj_fwd(c2, w2, out, B=B, Cc=cc, Mall=M, Tz=Tz))
+    g = timeit(lambda: K.cond_proj_dgrad(w2, dce, dc2, scratch, B=B, Cc=cc, Mall=M, Tz=Tz))
+    h = timeit(lambda: K.cond_proj_wgrad(c2, dce, dw2, B=B, Cc=cc, Mall=M, Tz=Tz))
+    print('cond_proj kernels, Cc = %3d: forward %6.1f us   input gradient (+ reduce) %6.1f us   weight gradient %6.1f us' % (cc, f, g, h), flush=True)

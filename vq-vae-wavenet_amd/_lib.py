@@ -137,6 +137,10 @@ SIGNATURES = {
     'vqw_softmax_xent': (_i, [_fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _fp]),
     'vqw_softmax_xent_fwd': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     'vqw_softmax_xent_bwd': (_i, [_fp, _fp, _fp, _f, _i, _i, _i, _fp]),
+    'vqw_cond_proj_fwd': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'vqw_cond_proj_wgrad': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _fp]),
+    'vqw_cond_proj_dgrad': (_i, [_fp, _fp, _fp, _fp, C.c_int64, _i, _i, _i, _i, _fp]),
+    'vqw_cond_proj_dgrad_scratch_floats': (_i, [_i, _i, _i, _i, C.POINTER(C.c_int64)]),
     'vqw_adam_ema_step': (_i, [_fp, _fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _f, _fp]),
     'vqw_adam_ema_step_guarded': (_i, [_fp, _fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _f, _fp, _fp]),
     'vqw_ar_decode_create': (_i, [C.POINTER(_fp), C.POINTER(ArWeights), _i]),

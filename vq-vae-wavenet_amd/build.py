@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build' + os.environ.get('VQW_BUILD_SUFFIX', ''))
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, os.environ.get('VQW_LIB_NAME', 'libvqwave.so'))
-SOURCES = ['common', 'conv_gemm', 'wgrad_gemm', 'pointwise', 'vq', 'wrappers', 'ar_decode', 'ar_persist', 'gate_f16x3']
+SOURCES = ['common', 'conv_gemm', 'wgrad_gemm', 'pointwise', 'cond_proj', 'vq', 'wrappers', 'ar_decode', 'ar_persist', 'gate_f16x3']
 # -pragma-unroll-threshold: the fully unrolled epilogues over 256 accumulator registers are longer than LLVM's default bound for
 # `#pragma unroll` (16 k instructions); a loop it leaves rolled indexes the accumulators dynamically, i.e. puts them in scratch
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-mllvm', '-pragma-unroll-threshold=65536'] + \

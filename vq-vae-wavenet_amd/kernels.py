@@ -594,6 +594,37 @@ def softmax_xent_bwd(logits, labels, *, dlogits, grad_scale=1.0):
     L.check(L.lib().vqw_softmax_xent_bwd(L.ptr(logits), L.ptr(labels), L.ptr(dlogits), float(grad_scale), B, Q, T, L.stream()))
 
 
+def cond_proj_fwd(cond, w, out, *, B, Cc, Mall, Tz):
+    """out[b][m][t] = sum_c w[c][m] cond[b][c][t]: every add_condition projection of the decoder in one launch (wavenet_ops.py:93-101)."""
+    _need(cond, B * Cc * Tz, 'cond')
+    _need(w, Cc * Mall, 'w')
+    _need(out, B * Mall * Tz, 'out')
+    L.check(L.lib().vqw_cond_proj_fwd(L.ptr(cond), L.ptr(w), L.ptr(out), B, Cc, Mall, Tz, L.stream()))
+
+
+def cond_proj_wgrad(cond, dce, dw, *, B, Cc, Mall, Tz):
+    """dw[c][m] += sum_{b,t} cond[b][c][t] dce[b][m][t] (dw: the zeroed gradient buffer)."""
+    _need(cond, B * Cc * Tz, 'cond')
+    _need(dce, B * Mall * Tz, 'dce')
+    _need(dw, Cc * Mall, 'dw')
+    L.check(L.lib().vqw_cond_proj_wgrad(L.ptr(cond), L.ptr(dce), L.ptr(dw), B, Cc, Mall, Tz, L.stream()))
+
+
+def cond_proj_dgrad_scratch(B, Cc, Mall, Tz):
+    n = C.c_int64(0)
+    L.check(L.lib().vqw_cond_proj_dgrad_scratch_floats(B, Cc, Mall, Tz, C.byref(n)))
+    return int(n.value)
+
+
+def cond_proj_dgrad(w, dce, dcond, scratch, *, B, Cc, Mall, Tz):
+    """dcond[b][c][t] = sum_m w[c][m] dce[b][m][t]; scratch: cond_proj_dgrad_scratch(...) floats."""
+    _need(w, Cc * Mall, 'w')
+    _need(dce, B * Mall * Tz, 'dce')
+    _need(dcond, B * Cc * Tz, 'dcond')
+    _need(scratch, cond_proj_dgrad_scratch(B, Cc, Mall, Tz), 'scratch')
+    L.check(L.lib().vqw_cond_proj_dgrad(L.ptr(w), L.ptr(dce), L.ptr(dcond), L.ptr(scratch), scratch.numel(), B, Cc, Mall, Tz, L.stream()))
+
+
 def adam_ema_step(param, grad, m, v, ema, *, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, decay=0.999,
                   grad_scale=1.0, skip=None):
     """skip: device int32 read when the kernel runs; non-zero = the step changes nothing (vqw_adam_ema_step_guarded)."""

@@ -154,6 +154,8 @@ class VQVAE:
         self.x3_void = torch.zeros(1, dtype=torch.int32, device=self.dev)      # deferred mode: a flagged step is waiting to be repeated
         self.defer_guard = os.environ.get('VQW_DEFER_GUARD', '0') == '1'       # read the range flag one step late (train_step)
         self._pending, self._void_host, self._void_slot, self._in_step = [], None, 0, False
+        # the condition projections (K = Cc ~ 80, rows of Tz ~ 104 frames) on their own fp32-MFMA kernels (csrc/cond_proj.hip)
+        self.cond_proj = self.Cc <= 128 and self.Mall % 4 == 0 and os.environ.get('VQW_COND_PROJ', '1') != '0'
         self.host_enqueue_ms = None
 
     # ------------------------------------------------------------------ parameter layout
@@ -650,8 +652,11 @@ class VQVAE:
         sc, am, flag, WS, head_x3, xpl, drop_th, drop_g, save = (plan[k] for k in ('sc', 'am', 'flag', 'WS', 'head_x3', 'xpl', 'drop_th',
                                                                                   'drop_g', 'save'))
         net = ws['net']
-        K.conv_gemm(x0=ws['cond'], w=P['cond_w'], out0=ws['condenc'], B=B, T_in=Tz, T_out=Tz, M=self.Mall,
-                    C0=self.Cc, taps=[0])                                                 # all add_condition 1x1s
+        if self.cond_proj:                                                                # all add_condition 1x1s
+            K.cond_proj_fwd(ws['cond'], P['cond_w'], ws['condenc'], B=B, Cc=self.Cc, Mall=self.Mall, Tz=Tz)
+        else:
+            K.conv_gemm(x0=ws['cond'], w=P['cond_w'], out0=ws['condenc'], B=B, T_in=Tz, T_out=Tz, M=self.Mall,
+                        C0=self.Cc, taps=[0])
         cbs = self.Mall * Tz
         ce_flat = ws['condenc'].view(-1)   # layer l's rows start at l*2R*Tz inside every batch block
         for l, d in enumerate(self.dil):
@@ -1090,8 +1095,15 @@ class VQVAE:
         K.conv_cin1_wgrad(ws['inputs'], dnet, G['pre_w'], k=self.pre_k, stride=1, offset=-(self.pre_k - 1))
         K.rowsum(dnet, total=G['pre_b'])
         # ---- local condition (wavenet_ops.py:93-101) -> d cond
-        K.wgrad_gemm(p=ws['cond'], q0=dce, dw=G['cond_w'], B=B, T_q=Tz, T_p=Tz, Cp=self.Cc, Q0=self.Mall, taps=[0])
-        K.conv_gemm(x0=dce, w=self._tt('cond_w'), out0=ws['dcond'], B=B, T_in=Tz, T_out=Tz, M=self.Cc, C0=self.Mall, taps=[0])
+        if self.cond_proj and Tz % 4 == 0 and P['cond_w'].data_ptr() % 16 == 0:
+            if 'cp_scratch' not in ws:
+                ws['cp_scratch'] = A.empty(K.cond_proj_dgrad_scratch(B, self.Cc, self.Mall, Tz), device=self.dev)
+                ws['_poison'].append(ws['cp_scratch'])
+            K.cond_proj_wgrad(ws['cond'], dce, G['cond_w'], B=B, Cc=self.Cc, Mall=self.Mall, Tz=Tz)
+            K.cond_proj_dgrad(P['cond_w'], dce, ws['dcond'], ws['cp_scratch'], B=B, Cc=self.Cc, Mall=self.Mall, Tz=Tz)
+        else:
+            K.wgrad_gemm(p=ws['cond'], q0=dce, dw=G['cond_w'], B=B, T_q=Tz, T_p=Tz, Cp=self.Cc, Q0=self.Mall, taps=[0])
+            K.conv_gemm(x0=dce, w=self._tt('cond_w'), out0=ws['dcond'], B=B, T_in=Tz, T_out=Tz, M=self.Cc, C0=self.Mall, taps=[0])
         if self.grad_sync is not None:      # decoder gradients are final: exchange them under the encoder backward
             self.grad_sync.bucket_ready(self.seg_off['pre_w'][0], self.n_flat)
         # ---- speaker embedding + VQ (model.py:22-27, 57-74, 99-106)
