@@ -9,11 +9,25 @@
 // products, fp32 accumulate: the arithmetic of the fp32 engine) straight from global memory -- lane (row, k half) of the MFMA is one
 // coalesced 4-byte load per operand, or where the contraction index is the contiguous one a 16-byte load that serves four MFMA steps
 // (the order of k inside a group is free as long as both operands use the same one) -- with no LDS, no barrier and enough
-// independent waves per SIMD to cover the load latency.  Plain fp32 FMA kernels were tried first: 78 / 191 / 105 us, the vector
+// independent waves per SIMD to cover the load latency: 36 / 38 / 53 us (tools/cond_bench.py).  What it took: the requests are
+// buffer loads whose out-of-range lanes read zero (a conditional load splits the loop into blocks that wait for every single
+// request: 54 / 46 / 66 us), the loops are hand-unrolled into double-buffered groups (hipcc leaves them rolled), and register use
+// is kept low enough for three or more waves per SIMD.  Plain fp32 FMA kernels were tried first: 78 / 191 / 105 us -- the vector
 // ALU's peak alone is 30 us for 2.1 GFLOP.
 #include "vqw_common.h"
 
 namespace {
+
+// Loads go through buffer resources: a lane that has nothing to load passes an offset behind the range and receives zero -- no
+// branch around the load (a conditional load splits the loop body into blocks that wait for every single request).
+constexpr int CP_OOB = (int)0x80000000;
+__device__ __forceinline__ float cp_ld1(__amdgpu_buffer_rsrc_t r, int off_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off_bytes, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cp_rsrc(const float* p, size_t floats) {
+    const size_t bytes = floats * 4;
+    return vqw_make_rsrc(p, bytes < 0x7fffffffull ? (unsigned)bytes : 0x7fffffffu);
+}
 
 __device__ __forceinline__ f32x16 cp_zero() {
     f32x16 z;
@@ -31,21 +45,39 @@ __global__ __launch_bounds__(256) void cond_proj_fwd_kernel(const float* __restr
     if (m0 >= Mall) return;
     const int m = m0 + l31;
     const bool mv = m < Mall;
-    const float* cb = cond + (size_t)b * Cc * Tz;
+    const __amdgpu_buffer_rsrc_t rw = cp_rsrc(w, (size_t)Cc * Mall), rc = cp_rsrc(cond + (size_t)b * Cc * Tz, (size_t)Cc * Tz);
     const int ksteps = (Cc + 1) >> 1;
     for (int t0 = 0; t0 < Tz; t0 += 128) {
         f32x16 acc[4] = {cp_zero(), cp_zero(), cp_zero(), cp_zero()};
-#pragma unroll 8
-        for (int k2 = 0; k2 < ksteps; ++k2) {
-            const int c = 2 * k2 + lhi;
-            const bool cv = c < Cc;
-            const float a = (cv && mv) ? w[(size_t)c * Mall + m] : 0.0f;
+        // groups of U contraction steps, double-buffered: the requests of the next group are in flight under the MFMAs of this one
+        // (hipcc does not unroll this loop on its own, and a rolled loop waits for every request)
+        // No masks: a row m >= Mall or a frame t >= Tz reads a neighbour's value and fills an output row / column that is never
+        // stored; c >= Cc (odd Cc, the last group's overshoot) lies behind both buffer ranges and reads as zero.
+        constexpr int U = 4;
+        float ga[2][U], gb[2][U][4];
+        const int aoff = (lhi * Mall + m) * 4, boff = (lhi * Tz + t0 + l31) * 4;
+        auto load_group = [&](int g, float (&a_)[U], float (&b_)[U][4]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = t0 + 32 * j + l31;
-                const float bv = (cv && t < Tz) ? cb[(size_t)c * Tz + t] : 0.0f;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                const int k2 = g * U + u;
+                a_[u] = cp_ld1(rw, aoff + k2 * (2 * Mall * 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b_[u][j] = cp_ld1(rc, boff + k2 * (2 * Tz * 4) + 128 * j);
             }
+        };
+        auto mfma_group = [&](const float (&a_)[U], const float (&b_)[U][4]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[u], b_[u][j], acc[j], 0, 0, 0);
+        };
+        const int ngroups = (ksteps + U - 1) / U;
+        load_group(0, ga[0], gb[0]);
+        for (int g = 0; g < ngroups; g += 2) {
+            load_group(g + 1, ga[1], gb[1]);
+            mfma_group(ga[0], gb[0]);
+            load_group(g + 2, ga[0], gb[0]);
+            if (g + 1 < ngroups) mfma_group(ga[1], gb[1]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -67,7 +99,7 @@ template <int CT>
 __global__ __launch_bounds__(256) void cond_proj_wgrad_kernel(const float* __restrict__ cond, const float* __restrict__ dce,
                                                               float* __restrict__ dw, int B, int Cc, int Mall, int Tz, int KS) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-    const int m0 = (blockIdx.x * 4 + wv) * 32, ks = blockIdx.y;
+    const int m0 = (blockIdx.x * 4 + wv) * 32, ks = blockIdx.y, cbase = blockIdx.z * 32 * CT;
     if (m0 >= Mall) return;
     const int m = m0 + l31;
     const bool mv = m < Mall;
@@ -75,25 +107,42 @@ __global__ __launch_bounds__(256) void cond_proj_wgrad_kernel(const float* __res
     f32x16 acc[CT];
 #pragma unroll
     for (int i = 0; i < CT; ++i) acc[i] = cp_zero();
-    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int b = b_lo; b < b_hi; ++b) {
-        const float* qrow = dce + ((size_t)b * Mall + (mv ? m : 0)) * Tz;
-        const float* cb = cond + (size_t)b * Cc * Tz;
-#pragma unroll 2
-        for (int t8 = 0; t8 < Tz; t8 += 8) {
-            const int t = t8 + 4 * lhi;
-            const bool tv = t < Tz;                     // (Tz % 4 == 0: a group of four is inside the row or behind it)
-            const f32x4 q = (mv && tv) ? *reinterpret_cast<const f32x4*>(qrow + t) : z4;
-            f32x4 p[CT];
+        // one resource per operand row block: the lane's own row of dce, the batch row of cond
+        const __amdgpu_buffer_rsrc_t rq = cp_rsrc(dce + (size_t)b * Mall * Tz, (size_t)Mall * Tz), rp = cp_rsrc(cond + (size_t)b * Cc * Tz, (size_t)Cc * Tz);
+        const int qoff = m * Tz * 4;
+        int poff[CT];
+        bool pv[CT];
 #pragma unroll
-            for (int i = 0; i < CT; ++i) {
-                const int c = 32 * i + l31;
-                p[i] = (c < Cc && tv) ? *reinterpret_cast<const f32x4*>(cb + (size_t)c * Tz + t) : z4;
+        for (int i = 0; i < CT; ++i) { pv[i] = cbase + 32 * i + l31 < Cc; poff[i] = (cbase + 32 * i + l31) * Tz * 4; }
+        // groups of U x 8 frames, double-buffered (see the forward kernel)
+        constexpr int U = 4;
+        f32x4 gq[2][U], gp[2][U][CT];
+        auto load_group = [&](int g, f32x4 (&q_)[U], f32x4 (&p_)[U][CT]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = (g * U + u) * 8 + 4 * lhi;
+                const bool tv = t < Tz;                     // (Tz % 4 == 0: a group of four is inside the row or behind it)
+                q_[u] = vqw_buf_load4(rq, (mv && tv) ? qoff + t * 4 : CP_OOB, 0);
+#pragma unroll
+                for (int i = 0; i < CT; ++i) p_[u][i] = vqw_buf_load4(rp, (pv[i] && tv) ? poff[i] + t * 4 : CP_OOB, 0);
             }
+        };
+        auto mfma_group = [&](const f32x4 (&q_)[U], const f32x4 (&p_)[U][CT]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int i = 0; i < CT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[i][j], q[j], acc[i], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(p_[u][i][j], q_[u][j], acc[i], 0, 0, 0);
+        };
+        const int ngroups = (Tz + 8 * U - 1) / (8 * U);
+        load_group(0, gq[0], gp[0]);
+        for (int g = 0; g < ngroups; g += 2) {
+            load_group(g + 1, gq[1], gp[1]);
+            mfma_group(gq[0], gp[0]);
+            load_group(g + 2, gq[0], gp[0]);
+            if (g + 1 < ngroups) mfma_group(gq[1], gp[1]);
         }
     }
     if (!mv) return;
@@ -101,7 +150,7 @@ __global__ __launch_bounds__(256) void cond_proj_wgrad_kernel(const float* __res
     for (int i = 0; i < CT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int c = 32 * i + (r >> 2) * 8 + lhi * 4 + (r & 3);
+            const int c = cbase + 32 * i + (r >> 2) * 8 + lhi * 4 + (r & 3);
             if (c >= Cc) continue;
             float* o = dw + (size_t)c * Mall + m;
             if (KS > 1) unsafeAtomicAdd(o, acc[i][r]);
@@ -116,31 +165,49 @@ template <int CT>
 __global__ __launch_bounds__(64) void cond_proj_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dce,
                                                              float* __restrict__ part, int B, int Cc, int Mall, int Tz, int chunk_m) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
-    const int chunk = blockIdx.x, t = blockIdx.y * 32 + l31, b = blockIdx.z;
+    const int nct = (Cc + 32 * CT - 1) / (32 * CT);
+    const int chunk = blockIdx.x, t = (blockIdx.y / nct) * 32 + l31, b = blockIdx.z, cbase = (blockIdx.y % nct) * 32 * CT;
     const int mlo = chunk * chunk_m, mhi = (mlo + chunk_m < Mall) ? mlo + chunk_m : Mall;
     const bool tv = t < Tz;
     f32x16 acc[CT];
 #pragma unroll
     for (int i = 0; i < CT; ++i) acc[i] = cp_zero();
-    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    const float* db = dce + (size_t)b * Mall * Tz + (tv ? t : 0);
-#pragma unroll 2
-    for (int m8 = mlo; m8 < mhi; m8 += 8) {
-        const int mm = m8 + 4 * lhi;
-        const bool kv = mm < mhi;                        // (chunk_m and Mall are multiples of 4)
-        float q[4];
+    const __amdgpu_buffer_rsrc_t rq = cp_rsrc(dce + (size_t)b * Mall * Tz, (size_t)Mall * Tz), rp = cp_rsrc(w, (size_t)Cc * Mall);
+    const int qoff = t * 4;
+    int poff[CT];
+    bool pv[CT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = (kv && tv) ? db[(size_t)(mm + j) * Tz] : 0.0f;
-        f32x4 p[CT];
+    for (int i = 0; i < CT; ++i) { pv[i] = cbase + 32 * i + l31 < Cc; poff[i] = (cbase + 32 * i + l31) * Mall * 4; }
+    // groups of U x 8 channels m, double-buffered (see the forward kernel)
+    constexpr int U = 4;
+    float gq[2][U][4];
+    f32x4 gp[2][U][CT];
+    auto load_group = [&](int g, float (&q_)[U][4], f32x4 (&p_)[U][CT]) {
 #pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int c = 32 * i + l31;
-            p[i] = (c < Cc && kv) ? *reinterpret_cast<const f32x4*>(w + (size_t)c * Mall + mm) : z4;
+        for (int u = 0; u < U; ++u) {
+            const int mm = mlo + (g * U + u) * 8 + 4 * lhi;
+            const bool kv = mm < mhi;                    // (chunk_m and Mall are multiples of 4: a group of four is inside the chunk or behind it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q_[u][j] = cp_ld1(rq, (kv && tv) ? qoff + (mm + j) * Tz * 4 : CP_OOB);
+#pragma unroll
+            for (int i = 0; i < CT; ++i) p_[u][i] = vqw_buf_load4(rp, (kv && pv[i]) ? poff[i] + mm * 4 : CP_OOB, 0);
         }
+    };
+    auto mfma_group = [&](const float (&q_)[U][4], const f32x4 (&p_)[U][CT]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int i = 0; i < CT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[i][j], q[j], acc[i], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < CT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(p_[u][i][j], q_[u][j], acc[i], 0, 0, 0);
+    };
+    const int ngroups = (mhi - mlo + 8 * U - 1) / (8 * U);
+    load_group(0, gq[0], gp[0]);
+    for (int g = 0; g < ngroups; g += 2) {
+        load_group(g + 1, gq[1], gp[1]);
+        mfma_group(gq[0], gp[0]);
+        load_group(g + 2, gq[0], gp[0]);
+        if (g + 1 < ngroups) mfma_group(gq[1], gp[1]);
     }
     if (!tv) return;
     float* pb = part + ((size_t)chunk * B + b) * Cc * Tz + t;
@@ -148,7 +215,7 @@ __global__ __launch_bounds__(64) void cond_proj_dgrad_kernel(const float* __rest
     for (int i = 0; i < CT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int c = 32 * i + (r >> 2) * 8 + lhi * 4 + (r & 3);
+            const int c = cbase + 32 * i + (r >> 2) * 8 + lhi * 4 + (r & 3);
             if (c < Cc) pb[(size_t)c * Tz] = acc[i][r];
         }
 }
@@ -188,10 +255,12 @@ int vqw_cond_proj_wgrad(const float* cond, const float* dce, float* dw, int B, i
     const int ct = (Cc + 31) / 32;
     // two batch ranges per column tile when one would leave most SIMDs without a wave (their sums meet by atomics: the caller's dw
     // is the zeroed gradient buffer, and two addends commute)
-    const int KS = (B >= 2 && vqw_cdiv(Mall, 32) < 4 * vqw_device_cus()) ? 2 : 1;
+    const int KS = (B >= 2 && vqw_cdiv(Mall, 32) * ct < 8 * vqw_device_cus()) ? 2 : 1;
     typedef void (*kfn_t)(const float*, const float*, float*, int, int, int, int, int);
-    const kfn_t kfn = ct == 1 ? cond_proj_wgrad_kernel<1> : (ct == 2 ? cond_proj_wgrad_kernel<2> : (ct == 3 ? cond_proj_wgrad_kernel<3> : cond_proj_wgrad_kernel<4>));
-    hipLaunchKernelGGL(kfn, dim3(vqw_cdiv(Mall, 128), KS), dim3(256), 0, (hipStream_t)s, cond, dce, dw, B, Cc, Mall, Tz, KS);
+    // one 32-row tile of c per wave (grid.z): three times the waves of an all-rows-per-wave layout, each re-reading its dce rows
+    // through L2 -- 44 -> 38 us: the kernel is bound by request latency, not by bytes
+    const kfn_t kfn = cond_proj_wgrad_kernel<1>;
+    hipLaunchKernelGGL(kfn, dim3(vqw_cdiv(Mall, 128), KS, ct), dim3(256), 0, (hipStream_t)s, cond, dce, dw, B, Cc, Mall, Tz, KS);
     VQW_LAUNCH_CHECK("vqw_cond_proj_wgrad");
     return 0;
 }
@@ -206,8 +275,8 @@ int vqw_cond_proj_dgrad(const float* w, const float* dce, float* dcond, float* s
     VQW_CHECK((size_t)scratch_floats >= (size_t)nchunk * n, "vqw_cond_proj_dgrad: scratch needs %d * B * Cc * Tz = %zu floats", nchunk, (size_t)nchunk * n);
     const int ct = (Cc + 31) / 32;
     typedef void (*kfn_t)(const float*, const float*, float*, int, int, int, int, int);
-    const kfn_t kfn = ct == 1 ? cond_proj_dgrad_kernel<1> : (ct == 2 ? cond_proj_dgrad_kernel<2> : (ct == 3 ? cond_proj_dgrad_kernel<3> : cond_proj_dgrad_kernel<4>));
-    hipLaunchKernelGGL(kfn, dim3(nchunk, vqw_cdiv(Tz, 32), B), dim3(64), 0, (hipStream_t)s, w, dce, scratch, B, Cc, Mall, Tz, chunk_m);
+    const kfn_t kfn = cond_proj_dgrad_kernel<1>;
+    hipLaunchKernelGGL(kfn, dim3(nchunk, vqw_cdiv(Tz, 32) * ct, B), dim3(64), 0, (hipStream_t)s, w, dce, scratch, B, Cc, Mall, Tz, chunk_m);
     hipLaunchKernelGGL(cond_proj_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, (const float*)scratch, dcond, nchunk, n);
     VQW_LAUNCH_CHECK("vqw_cond_proj_dgrad");
     return 0;
