@@ -805,6 +805,19 @@ def test_pack_weights_from_transposed_storage(K, mode):
     K.f16x3_pack_weights(w2.t().contiguous(), want2, 64, Cin, Cin, 1.0, mode=mode)
     K.f16x3_pack_weights_t(w2, got2, 64, Cin, 64, Cout, 0, 1.0, mode=mode)
     assert torch.equal(want2.view(torch.int16), got2.view(torch.int16))
+    # blocks of k that are not multiples of 64 (the direct kernel instead of the LDS-transposing one), M not a multiple of 64
+    w3 = torch.randn(2, 72, 40, generator=gen).to(DEV)                            # [tap][m = 72][k_inner = 40]
+    n3 = 2 * 80 * 72
+    want3, got3 = torch.zeros(n3, dtype=torch.float16, device=DEV), torch.zeros(n3, dtype=torch.float16, device=DEV)
+    K.f16x3_pack_weights(w3.permute(0, 2, 1).contiguous(), want3, 80, 72, 72, 1.0, mode=mode)
+    K.f16x3_pack_weights_t(w3, got3, 80, 72, 40, 40, 72 * 40, 1.0, mode=mode)
+    assert torch.equal(want3.view(torch.int16), got3.view(torch.int16))
+    w4 = torch.randn(72, 128, generator=gen).to(DEV)                              # tile kernel with a partial column tile (M = 72)
+    n4 = 2 * 128 * 72
+    want4, got4 = torch.zeros(n4, dtype=torch.float16, device=DEV), torch.zeros(n4, dtype=torch.float16, device=DEV)
+    K.f16x3_pack_weights(w4.t().contiguous(), want4, 128, 72, 72, 1.0, mode=mode)
+    K.f16x3_pack_weights_t(w4, got4, 128, 72, 128, 128, 0, 1.0, mode=mode)
+    assert torch.equal(want4.view(torch.int16), got4.view(torch.int16))
 
 
 @pytest.mark.parametrize('half', [0, 1])
