@@ -114,6 +114,7 @@ class VQVAE:
         self.x3_mode_skip = half('VQW_X3_HALF_SKIP', '0')                                  # the all-layers skip contraction
         self.x3_mode_bwd = half('VQW_X3_HALF_BWD', '1')                                    # gate backward
         self.x3_mode_dgrad = half('VQW_X3_HALF_DGRAD', '0')                                # input gradient
+        self.x3_mode_head = half('VQW_X3_HALF_HEAD', '1')                                  # postprocess1 / 2 and their input gradients
         self.x3_guard = engine == 'f16x3' and ladder == '0' and not self.bf16
         self.x3_all = self.x3_guard or self.bf16          # the plane engine carries every decoder contraction, or none
         if self.x3_all:
@@ -705,9 +706,9 @@ class VQVAE:
             K.f16x3_out_conv(epi=2, xp=ws['hp'], Cin=S, wp=ws['wpost1'], bias=P['post1_b'], cond=ce_flat[L * 2 * R * Tz:], cond_T=Tz,
                              cond_bstride=cbs, net_out=ws['h1'], net_out_planes=ws['hp2'], relu_planes=True, B=B, T=T, R=S, S=0,
                              w_scale_inv=1.0, x_scale=sc('SK'), w_scale=sc('WH'), out_scale=sc('H1'), out_amax=am('H1'), flag=flag,
-                             mode=md)
+                             mode=self.x3_mode_head)
             K.f16x3_out_conv(epi=2, xp=ws['hp2'], Cin=S, wp=ws['wpost2'], bias=P['post2_b'], net_out=ws['logits'], B=B, T=T, R=Q,
-                             S=0, w_scale_inv=1.0, x_scale=sc('H1'), w_scale=sc('WH'), mode=md)
+                             S=0, w_scale_inv=1.0, x_scale=sc('H1'), w_scale=sc('WH'), mode=self.x3_mode_head)
             return
         for gi in range(ngrp if f16x3_skip else 0):   # skip = skip0 + sum_l (W_s,l g_l + b_s,l)   (wavenet.py:72 summed over the layers)
             K.f16x3_out_conv(xp=ws['gp'], Cin=Lg * R, xp_kc0=gi * Lg * (R // 8), xp_KC=L * (R // 8), wp=wsk[gi],
@@ -851,14 +852,14 @@ class VQVAE:
                           p_scale=hsc('H1'), q0_scale=dl, q_total=G['post2_b'], mode=mdh)
             K.f16x3_out_conv(epi=2, xp=ws['hp2'], Cin=Q, wp=ws['wpost2t'], net_out=h1, aux0=h1, net_out_planes=ws['hp'], B=B, T=T,
                              R=S, S=0, w_scale_inv=1.0, x_scale=dl, w_scale=hsc('WH'), out_scale=hsc('DH'), out_amax=ham('DH'),
-                             flag=hflag, mode=mdh)                 # h1 := d h1 (pre-relu)
+                             flag=hflag, mode=self.x3_mode_head)   # h1 := d h1 (pre-relu)
             # ---- postprocess1 (wavenet.py:79-88)
             K.f16x3_wgrad(p=skip, p_relu=True, q0=h1, dw=G['post1_w'], slab=ws['wslab'], B=B, T=T, Cp=S, Q0=S, taps=[0],
                           p_scale=hsc('SK'), q0_scale=hsc('DH'), q_total=G['post1_b'], q_seg=dce.view(-1)[L * 2 * R * Tz:], seg_T=Tz,
                           seg_bstride=cbs, mode=mdh)
             K.f16x3_out_conv(epi=2, xp=ws['hp'], Cin=S, wp=ws['wpost1t'], net_out=skip, aux0=skip, net_out_planes=ws['gr'],
                              planes_kc0=0, planes_KC=(S + R) // 8, plane_scale=GSh, B=B, T=T, R=S, S=0, w_scale_inv=1.0, x_scale=hsc('DH'),
-                             w_scale=hsc('WH'), out_scale=hsc('G'), out_amax=ham('G'), flag=hflag, mode=mdh)   # skip := d skip, and its planes
+                             w_scale=hsc('WH'), out_scale=hsc('G'), out_amax=ham('G'), flag=hflag, mode=self.x3_mode_head)   # skip := d skip, and its planes
         else:
             # ---- postprocess2 (wavenet.py:93-96)
             K.wgrad_gemm(p=h1, p_relu=True, q0=dlog, dw=G['post2_w'], B=B, T_q=T, T_p=T, Cp=S, Q0=Q, taps=[0])
