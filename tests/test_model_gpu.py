@@ -173,6 +173,17 @@ def test_default_width_short_segment(pkg):
     print('worst grad', worst)
 
 
+def test_default_width_with_the_round3_paths_switched_off(pkg, monkeypatch):
+    """The paths round 3 replaced stay in the code behind switches (and under shapes the new ones do not take): the condition
+    projections on the conv engine (VQW_COND_PROJ=0), the short encoder layers without split-K (VQW_SCONV_SPLIT=0), the weight
+    gradients one layer per launch from fp32 operands (VQW_WGRAD_BATCH=0).  Same problem and bars as the test above."""
+    for k in ('VQW_COND_PROJ', 'VQW_SCONV_SPLIT', 'VQW_WGRAD_BATCH'):
+        monkeypatch.setenv(k, '0')
+    m, w = dict(M.DEFAULT_MODEL), dict(M.DEFAULT_WAVENET)
+    worst = run_parity(pkg, m, w, 109, 1, 1024, seed=3, steps=1, grad_tol=5e-3, err=l2err, check_params=False)
+    print('worst grad', worst)
+
+
 @pytest.mark.parametrize('mode', ['1', '2', '3', '4', '5'])
 def test_default_width_gate_f16x3(pkg, monkeypatch, mode):
     """The same parity run on the development ladder of the fp16x3 engine (VQW_GATE_F16X3=1..5: fixed scales, no guards):
